@@ -1,0 +1,31 @@
+# Top-level build: libc2d.so (HIP, gfx950 only), the CPU oracle, and the CLI drivers.
+PKG      := convex-2d-gpu-collision-detection_amd
+CSRC     := $(PKG)/csrc
+LIBDIR   := $(PKG)/lib
+HIPCC    ?= /opt/rocm/bin/hipcc
+# -ffp-contract=off is part of the arithmetic contract: no implicit FMA.
+HIPFLAGS := -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -Wall -Wextra -Wno-unused-parameter -Iinclude
+
+SRCS := $(CSRC)/c2d_api.hip $(CSRC)/c2d_sat.hip $(CSRC)/c2d_mc.hip
+OBJS := $(SRCS:.hip=.o)
+HDRS := $(CSRC)/c2d_math.hpp $(CSRC)/c2d_internal.hpp include/c2d.h include/utils.h
+
+all: lib oracle
+
+lib: $(LIBDIR)/libc2d.so
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIBDIR)/libc2d.so: $(OBJS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(OBJS)
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -f $(OBJS) $(LIBDIR)/libc2d.so
+	$(MAKE) -C oracle clean
+
+.PHONY: all lib oracle clean

@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the c2d hot path on MI355X.
+
+Metric (BASELINE.json): rectangle-pair SAT tests per second, whole job, inputs
+resident in HBM, on BASELINE config 2: 10^7 random OBB pairs per GPU as 16 SoA
+vertex planes -> u8 booleans (65 algorithmic bytes per pair).  One "step" = one
+pass of c2d_sat_rect_pairs_verts over the rank's 10^7 pairs.  With N > 1 every
+rank owns its own 10^7 pairs (weak scaling, no data-path collective) and one
+RCCL all-reduce of the colliding-pair count closes the timed region.
+
+The same JSON line also carries
+  roofline     — HBM roofline of the SAT kernel (HIP events on its stream),
+  cpu_baseline — the CPU oracle (OpenMP port of the reference arithmetic) timed on
+                 a bounded sample of the same workload on this host, rank 0, N = 1,
+  mc           — Monte-Carlo samples/s of BASELINE config 3 (1 scene, 10^8
+                 samples per GPU, sample ranges sharded over ranks, one all-reduce
+                 of the hit count), with its VALU-roofline note.
+
+Launch: `python bench.py [--gpus N --steps K --warmup W]`; for N > 1 under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_PER_PAIR = 65            # 16 planes x 4 B read + 1 B written
+FP32_VALU_PEAK_TFLOPS = 157.3  # spec, FMA counted as 2
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--pairs", type=int, default=10_000_000, help="rectangle pairs per GPU (config 2: 1e7)")
+    ap.add_argument("--mc-samples", type=int, default=100_000_000, help="MC samples per GPU (config 3: 1e8)")
+    ap.add_argument("--mc-reps", type=int, default=5)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target wall time of the CPU baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mc", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from __graft_entry__ import load_package
+
+    pkg = load_package()
+    import importlib
+
+    wl = importlib.import_module("c2d_amd.workloads")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    eng = pkg.Engine(local_rank)  # raises if libc2d.so is missing or the device is not gfx950
+    stream = torch.cuda.Stream(device=dev)
+    sh = stream.cuda_stream
+
+    # ---- workload: config 2, resident in HBM -----------------------------------------
+    n = args.pairs
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x5A7 + rank)
+    pose = torch.empty((10, n), dtype=torch.float32, device=dev)
+    for r in range(2):
+        pose[5 * r + 0].uniform_(-8.0, 8.0, generator=gen)
+        pose[5 * r + 1].uniform_(-8.0, 8.0, generator=gen)
+        pose[5 * r + 2].uniform_(0.1, 5.0, generator=gen)
+        pose[5 * r + 3].uniform_(0.1, 5.0, generator=gen)
+        pose[5 * r + 4].uniform_(0.0, 2.0 * np.pi, generator=gen)
+    planes = torch.empty((16, n), dtype=torch.float32, device=dev)
+    out = torch.empty(n, dtype=torch.uint8, device=dev)
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    row = lambda t, k: t.data_ptr() + k * t.stride(0) * t.element_size()  # noqa: E731
+    for r in range(2):
+        eng.rects_from_poses(*[row(pose, 5 * r + k) for k in range(5)], n, [row(planes, 8 * r + k) for k in range(8)], stream=sh)
+    plane_ptrs = [row(planes, k) for k in range(16)]
+    torch.cuda.synchronize()
+    del pose
+
+    def step():
+        eng.sat_rect_pairs_verts(plane_ptrs, n, out.data_ptr(), count.data_ptr(), stream=sh)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    count.zero_()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    total_count = count
+    if world > 1:
+        with torch.cuda.stream(stream):
+            dist.all_reduce(count, op=dist.ReduceOp.SUM)  # the single RCCL reduce of the hit counts
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # average launch duration on the kernel's stream
+    pairs_total = n * world * args.steps
+    value = pairs_total / elapsed
+    collide_rate = float(total_count.item()) / (n * world * args.steps)
+
+    achieved_gbs = BYTES_PER_PAIR * n / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "sat_rect_verts_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if int(tj.get("pairs", 0)) == n:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "sat_rect_verts_kernel<4>", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": BYTES_PER_PAIR * n, "kernel_ms": round(kernel_ms, 5)}
+
+    # ---- Monte-Carlo leg: config 3 --------------------------------------------------------
+    mc = None
+    if not args.no_mc:
+        sc = wl.MC_PAIR_SCENE
+        hits = torch.zeros(1, dtype=torch.int64, device=dev)
+        S = args.mc_samples
+
+        def mc_step():
+            # rank r evaluates samples [r*S, (r+1)*S) of stream (seed 1234, scene 0)
+            eng.mc_pair(sc["robot_w"], sc["robot_h"], sc["pos"], sc["pose"], sc["std_dev"], 1234, 0, rank * S, S,
+                        hits.data_ptr(), stream=sh)
+
+        mc_step()
+        torch.cuda.synchronize()
+        hits.zero_()
+        barrier()
+        torch.cuda.synchronize()
+        m0 = time.perf_counter()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(args.mc_reps):
+            mc_step()
+        e1.record(stream)
+        if world > 1:
+            with torch.cuda.stream(stream):
+                dist.all_reduce(hits, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        barrier()
+        m1 = time.perf_counter()
+        mel = m1 - m0
+        if world > 1:
+            tm = torch.tensor([mel], dtype=torch.float64, device=dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            mel = float(tm.item())
+        mc_kernel_ms = e0.elapsed_time(e1) / args.mc_reps
+        p = float(hits.item()) / (S * world * args.mc_reps)
+        mc = {"metric": "mc_samples_per_s", "value": S * world * args.mc_reps / mel, "samples_per_gpu": S, "reps": args.mc_reps,
+              "kernel_ms": round(mc_kernel_ms, 4), "probability": p, "scene": "config3: robot 4.07x1.74 at (3,1) th=0.6, obstacle 2x1, sigma=(.3,.3,.2,0,0)",
+              "bound": "valu", "note": "~0 HBM bytes per sample; VALU/transcendental bound (DESIGN.md)"}
+
+    # ---- CPU baseline: oracle port on this host, rank 0, N = 1 only ------------------------------
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import cpu as oracle  # checker / reported baseline only
+
+        m = min(n, 2_000_000)
+        host_planes = planes[:, :m].contiguous().cpu().numpy()
+        gpu_out = out[:m].cpu().numpy()
+        ref, _ = oracle.sat_rect_pairs_verts(host_planes)  # warm-up + parity check of the sample
+        if not np.array_equal(ref, gpu_out):
+            raise SystemExit("PARITY FAILURE: GPU booleans differ from the CPU oracle on the bench sample")
+        reps, c0 = 0, time.perf_counter()
+        while True:
+            oracle.sat_rect_pairs_verts(host_planes)
+            reps += 1
+            if time.perf_counter() - c0 >= args.cpu_seconds:
+                break
+        cel = time.perf_counter() - c0
+        cpu_baseline = {"value": m * reps / cel, "unit": "pair_tests/s", "cores": oracle.num_threads(), "kind": "port",
+                        "sample": f"first {m} pairs of the workload x {reps} passes ({cel:.1f} s), OpenMP, booleans checked equal to the GPU's"}
+        if mc is not None:
+            ms = 2_000_000
+            c0 = time.perf_counter()
+            h = oracle.mc_pair(sc["robot_w"], sc["robot_h"], sc["pos"], sc["pose"], sc["std_dev"], 1234, 0, 0, ms)
+            cel = time.perf_counter() - c0
+            mc["cpu_baseline"] = {"value": ms / cel, "unit": "samples/s", "cores": oracle.num_threads(), "kind": "port",
+                                  "sample": f"first {ms} samples of the same stream", "probability": h / ms}
+
+    if rank == 0:
+        line = {
+            "metric": "sat_pair_tests_per_s", "value": value, "unit": "pair_tests/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "config2: 1e7 random OBB pairs per GPU, 16 SoA vertex planes -> u8 booleans, single SAT overlap kernel",
+                       "pairs_per_gpu": n, "bytes_per_pair": BYTES_PER_PAIR, "collide_rate": round(collide_rate, 5),
+                       "parallelism": f"pairs sharded over {world} GPU(s), one RCCL all-reduce of the hit count"},
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "mc": mc,
+            "device": eng.info()["name"],
+        }
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

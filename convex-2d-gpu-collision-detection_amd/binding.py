@@ -1,0 +1,298 @@
+"""ctypes mirror of include/c2d.h.
+
+Every method maps one-to-one onto a C-ABI entry point; argument names and
+meaning follow the header (which cites the reference lines each call replaces).
+Device pointers are plain integers, so buffers may come from ``Engine.malloc``
+or from any other allocator on the same device (e.g. ``torch.Tensor.data_ptr()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+KMAX = 16
+
+POSE_DT = np.dtype([("width", "<f4"), ("height", "<f4"), ("theta", "<f4")])
+STD_DT = np.dtype([("x", "<f4"), ("y", "<f4"), ("theta", "<f4"), ("width", "<f4"), ("height", "<f4")])
+SCENE_DT = np.dtype([("x", "<f4"), ("y", "<f4"), ("var_idx", "<f4"), ("pose_idx", "<f4")])
+ROW_DT = np.dtype([("x", "<f4"), ("y", "<f4"), ("cp", "<f4"), ("var_idx", "<f4"), ("pose_idx", "<f4")])
+
+
+class C2DError(RuntimeError):
+    def __init__(self, status: int, what: str, detail: str = ""):
+        self.status = status
+        super().__init__(f"{what}: status {status}" + (f" ({detail})" if detail else ""))
+
+
+class _Position(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float)]
+
+
+class _Pose(C.Structure):
+    _fields_ = [("width", C.c_float), ("height", C.c_float), ("theta", C.c_float)]
+
+
+class _StdDev(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("theta", C.c_float), ("width", C.c_float), ("height", C.c_float)]
+
+
+class _DeviceInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 128), ("arch", C.c_char * 64), ("device", C.c_int), ("compute_units", C.c_int),
+                ("wavefront_size", C.c_int), ("lds_bytes_per_cu", C.c_int), ("hbm_bytes", C.c_size_t)]
+
+
+class _McScenesArgs(C.Structure):
+    _fields_ = [
+        ("d_poses", C.c_void_p), ("num_poses", C.c_uint32),
+        ("d_std_devs", C.c_void_p), ("num_std_devs", C.c_uint32),
+        ("d_scenes", C.c_void_p), ("n_scenes", C.c_size_t),
+        ("robot_w", C.c_float), ("robot_h", C.c_float),
+        ("accuracy_bins", C.POINTER(C.c_float)), ("bin_accuracy", C.POINTER(C.c_float)),
+        ("n_accuracy_bins", C.c_uint32), ("max_samples", C.c_uint32),
+        ("seed", C.c_uint64), ("scene_id_base", C.c_uint64),
+        ("d_hits", C.c_void_p), ("d_n_used", C.c_void_p), ("d_rows", C.c_void_p),
+        ("total_samples", C.POINTER(C.c_uint64)), ("iterations", C.POINTER(C.c_uint32)),
+    ]
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, "lib", "libc2d.so")
+
+
+_lib: Optional[C.CDLL] = None
+
+# name -> (restype, argtypes); also the list of symbols the header declares
+_SIGNATURES = {
+    "c2d_version": (C.c_int, []),
+    "c2d_status_string": (C.c_char_p, [C.c_int]),
+    "c2d_last_error": (C.c_char_p, [C.c_void_p]),
+    "c2d_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "c2d_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "c2d_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "c2d_ctx_info": (C.c_int, [C.c_void_p, C.POINTER(_DeviceInfo)]),
+    "c2d_malloc": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]),
+    "c2d_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "c2d_memset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
+    "c2d_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "c2d_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "c2d_stream_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "c2d_stream_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "c2d_stream_synchronize": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "c2d_rects_from_poses": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_size_t, C.POINTER(C.c_void_p), C.c_void_p]),
+    "c2d_sat_rect_pairs_verts": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "c2d_sat_rect_pairs_pose": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "c2d_sat_poly_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "c2d_philox_normals": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "c2d_mc_pair": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.POINTER(_Position), C.POINTER(_Pose), C.POINTER(_StdDev),
+                              C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "c2d_mc_scenes": (C.c_int, [C.c_void_p, C.POINTER(_McScenesArgs), C.c_void_p]),
+    "c2d_sample_scenes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_float,
+                                    C.c_uint64, C.c_uint64, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "c2d_calc_slack": (C.c_float, [C.c_uint32, C.c_uint32]),
+    "c2d_get_bin": (C.c_int, [C.c_float, C.POINTER(C.c_float), C.c_uint32]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def load_library() -> C.CDLL:
+    """dlopen lib/libc2d.so and type every entry point.  Raises if the HIP
+    library has not been built: there is no fallback."""
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise C2DError(-3, "libc2d.so not built", f"run `make lib` or __graft_entry__.build(); expected {path}")
+        lib = C.CDLL(path)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+class DeviceArray:
+    """A device allocation owned by an Engine, with numpy-like metadata."""
+
+    def __init__(self, eng: "Engine", ptr: int, shape, dtype):
+        self.eng, self.ptr, self.shape, self.dtype = eng, ptr, tuple(shape), np.dtype(dtype)
+
+    @property
+    def nbytes(self) -> int:
+        return int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+
+    def row(self, i: int) -> int:
+        """device pointer of sub-array [i] of a C-contiguous array"""
+        inner = int(np.prod(self.shape[1:], dtype=np.int64)) * self.dtype.itemsize
+        return self.ptr + i * inner
+
+    def get(self, stream: int = 0) -> np.ndarray:
+        return self.eng.to_host(self, stream)
+
+    def free(self):
+        if self.ptr:
+            self.eng.free(self.ptr)
+            self.ptr = 0
+
+
+def _ptr_of(x) -> int:
+    if isinstance(x, DeviceArray):
+        return x.ptr
+    if x is None:
+        return 0
+    return int(x)
+
+
+class Engine:
+    """One c2d_ctx (one device)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        st = self.lib.c2d_ctx_create(device, C.byref(h))
+        if st != 0:
+            raise C2DError(st, "c2d_ctx_create", self.lib.c2d_status_string(st).decode())
+        self.h = h
+        self.device = device
+
+    # -- plumbing -----------------------------------------------------------
+    def _check(self, st: int, what: str):
+        if st != 0:
+            raise C2DError(st, what, self.lib.c2d_last_error(self.h).decode() or self.lib.c2d_status_string(st).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.c2d_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self) -> dict:
+        di = _DeviceInfo()
+        self._check(self.lib.c2d_ctx_info(self.h, C.byref(di)), "c2d_ctx_info")
+        return {"name": di.name.decode(), "arch": di.arch.decode(), "device": di.device, "compute_units": di.compute_units,
+                "wavefront_size": di.wavefront_size, "lds_bytes_per_cu": di.lds_bytes_per_cu, "hbm_bytes": di.hbm_bytes}
+
+    def malloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self._check(self.lib.c2d_malloc(self.h, C.byref(p), nbytes), "c2d_malloc")
+        return p.value or 0
+
+    def free(self, ptr: int):
+        self._check(self.lib.c2d_free(self.h, C.c_void_p(ptr)), "c2d_free")
+
+    def memset(self, ptr, value: int, nbytes: int, stream: int = 0):
+        self._check(self.lib.c2d_memset(self.h, C.c_void_p(_ptr_of(ptr)), value, nbytes, C.c_void_p(stream)), "c2d_memset")
+
+    def synchronize(self, stream: int = 0):
+        self._check(self.lib.c2d_stream_synchronize(self.h, C.c_void_p(stream)), "c2d_stream_synchronize")
+
+    def stream_create(self) -> int:
+        s = C.c_void_p()
+        self._check(self.lib.c2d_stream_create(self.h, C.byref(s)), "c2d_stream_create")
+        return s.value or 0
+
+    def stream_destroy(self, stream: int):
+        self._check(self.lib.c2d_stream_destroy(self.h, C.c_void_p(stream)), "c2d_stream_destroy")
+
+    def empty(self, shape, dtype) -> DeviceArray:
+        if isinstance(shape, int):
+            shape = (shape,)
+        a = DeviceArray(self, 0, shape, dtype)
+        a.ptr = self.malloc(max(a.nbytes, 1))
+        return a
+
+    def zeros(self, shape, dtype, stream: int = 0) -> DeviceArray:
+        a = self.empty(shape, dtype)
+        self.memset(a.ptr, 0, max(a.nbytes, 1), stream)
+        return a
+
+    def to_device(self, host: np.ndarray, stream: int = 0) -> DeviceArray:
+        host = np.ascontiguousarray(host)
+        a = self.empty(host.shape, host.dtype)
+        if host.nbytes:
+            self._check(self.lib.c2d_memcpy_h2d(self.h, C.c_void_p(a.ptr), C.c_void_p(host.ctypes.data), host.nbytes,
+                                                C.c_void_p(stream)), "c2d_memcpy_h2d")
+            self.synchronize(stream)
+        return a
+
+    def to_host(self, a: DeviceArray, stream: int = 0) -> np.ndarray:
+        out = np.empty(a.shape, a.dtype)
+        if out.nbytes:
+            self._check(self.lib.c2d_memcpy_d2h(self.h, C.c_void_p(out.ctypes.data), C.c_void_p(a.ptr), out.nbytes,
+                                                C.c_void_p(stream)), "c2d_memcpy_d2h")
+            self.synchronize(stream)
+        return out
+
+    def read(self, ptr: int, shape, dtype, stream: int = 0) -> np.ndarray:
+        return self.to_host(DeviceArray(self, ptr, shape, dtype), stream)
+
+    # -- geometry -------------------------------------------------------------
+    def rects_from_poses(self, cx, cy, w, h, theta, n: int, out_planes: Sequence, stream: int = 0):
+        arr = (C.c_void_p * 8)(*[_ptr_of(p) for p in out_planes])
+        self._check(self.lib.c2d_rects_from_poses(self.h, _ptr_of(cx), _ptr_of(cy), _ptr_of(w), _ptr_of(h), _ptr_of(theta),
+                                                  n, arr, C.c_void_p(stream)), "c2d_rects_from_poses")
+
+    def sat_rect_pairs_verts(self, planes: Sequence, n: int, out, count=None, stream: int = 0):
+        if len(planes) != 16:
+            raise ValueError("need 16 vertex planes")
+        arr = (C.c_void_p * 16)(*[_ptr_of(p) for p in planes])
+        self._check(self.lib.c2d_sat_rect_pairs_verts(self.h, arr, n, _ptr_of(out), _ptr_of(count), C.c_void_p(stream)),
+                    "c2d_sat_rect_pairs_verts")
+
+    def sat_rect_pairs_pose(self, planes: Sequence, n: int, out, count=None, stream: int = 0):
+        if len(planes) != 10:
+            raise ValueError("need 10 pose planes")
+        arr = (C.c_void_p * 10)(*[_ptr_of(p) for p in planes])
+        self._check(self.lib.c2d_sat_rect_pairs_pose(self.h, arr, n, _ptr_of(out), _ptr_of(count), C.c_void_p(stream)),
+                    "c2d_sat_rect_pairs_pose")
+
+    def sat_poly_pairs(self, vx, vy, k, n: int, out, count=None, stream: int = 0):
+        self._check(self.lib.c2d_sat_poly_pairs(self.h, _ptr_of(vx), _ptr_of(vy), _ptr_of(k), n, _ptr_of(out), _ptr_of(count),
+                                                C.c_void_p(stream)), "c2d_sat_poly_pairs")
+
+    # -- random stream / Monte-Carlo ------------------------------------------------
+    def philox_normals(self, seed: int, scene_id: int, sample_begin: int, n: int, normals, raw=None, stream: int = 0):
+        self._check(self.lib.c2d_philox_normals(self.h, seed, scene_id, sample_begin, n, _ptr_of(normals), _ptr_of(raw),
+                                                C.c_void_p(stream)), "c2d_philox_normals")
+
+    def mc_pair(self, robot_w, robot_h, pos, pose, std_dev, seed, scene_id, sample_begin, n_samples, hits, stream: int = 0):
+        self._check(self.lib.c2d_mc_pair(self.h, robot_w, robot_h, C.byref(_Position(*pos)), C.byref(_Pose(*pose)),
+                                         C.byref(_StdDev(*std_dev)), seed, scene_id, sample_begin, n_samples,
+                                         _ptr_of(hits), C.c_void_p(stream)), "c2d_mc_pair")
+
+    def mc_scenes(self, poses, num_poses, std_devs, num_std_devs, scenes, n_scenes, robot_w, robot_h, accuracy_bins,
+                  bin_accuracy, max_samples, seed, scene_id_base, hits, n_used, rows=None, stream: int = 0):
+        bins = np.ascontiguousarray(accuracy_bins, dtype=np.float32)
+        acc = np.ascontiguousarray(bin_accuracy, dtype=np.float32)
+        if len(acc) != len(bins) - 1:
+            raise ValueError("bin_accuracy must have len(accuracy_bins) - 1 entries")
+        total, iters = C.c_uint64(0), C.c_uint32(0)
+        a = _McScenesArgs(_ptr_of(poses), num_poses, _ptr_of(std_devs), num_std_devs, _ptr_of(scenes), n_scenes, robot_w,
+                          robot_h, bins.ctypes.data_as(C.POINTER(C.c_float)), acc.ctypes.data_as(C.POINTER(C.c_float)),
+                          len(bins), max_samples, seed, scene_id_base, _ptr_of(hits), _ptr_of(n_used), _ptr_of(rows),
+                          C.pointer(total), C.pointer(iters))
+        self._check(self.lib.c2d_mc_scenes(self.h, C.byref(a), C.c_void_p(stream)), "c2d_mc_scenes")
+        return int(total.value), int(iters.value)
+
+    def sample_scenes(self, poses, num_poses, std_devs, num_std_devs, robot_w, robot_h, spread, seed, scene_id_base,
+                      n_scenes, scenes, stream: int = 0):
+        self._check(self.lib.c2d_sample_scenes(self.h, _ptr_of(poses), num_poses, _ptr_of(std_devs), num_std_devs, robot_w,
+                                               robot_h, spread, seed, scene_id_base, n_scenes, _ptr_of(scenes),
+                                               C.c_void_p(stream)), "c2d_sample_scenes")
+
+    def calc_slack(self, n: int, k: int) -> float:
+        return float(self.lib.c2d_calc_slack(n, k))
+
+    def get_bin(self, p: float, bins) -> int:
+        b = np.ascontiguousarray(bins, dtype=np.float32)
+        return int(self.lib.c2d_get_bin(p, b.ctypes.data_as(C.POINTER(C.c_float)), len(b)))

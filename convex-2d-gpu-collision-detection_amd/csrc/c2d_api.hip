@@ -1,0 +1,161 @@
+// c2d_api.hip — context, memory and stream plumbing of the C-ABI (include/c2d.h).
+// Replaces the cudaMalloc / cudaMemcpy / cudaFree / error-macro scaffolding of the
+// reference mains (compute_collision_probability.cu:212-251, utils.cu:59-72).
+#include "c2d_internal.hpp"
+
+extern "C" {
+
+int c2d_version(void) { return C2D_VERSION_MAJOR * 1000 + C2D_VERSION_MINOR; }
+
+const char* c2d_status_string(int status)
+{
+    switch (status) {
+    case C2D_OK: return "ok";
+    case C2D_ERR_INVALID_ARG: return "invalid argument";
+    case C2D_ERR_HIP: return "HIP runtime error";
+    case C2D_ERR_NO_DEVICE: return "no usable device";
+    case C2D_ERR_NOMEM: return "out of memory";
+    case C2D_ERR_UNSUPPORTED: return "unsupported argument combination";
+    default: return "unknown status";
+    }
+}
+
+const char* c2d_last_error(const c2d_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int c2d_device_count(int* count)
+{
+    if (!count) return C2D_ERR_INVALID_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { *count = 0; return C2D_ERR_NO_DEVICE; }
+    *count = n;
+    return C2D_OK;
+}
+
+int c2d_ctx_create(int device, c2d_ctx** out)
+{
+    if (!out) return C2D_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return C2D_ERR_NO_DEVICE;
+    c2d_ctx* ctx = new (std::nothrow) c2d_ctx();
+    if (!ctx) return C2D_ERR_NOMEM;
+    ctx->device = device;
+    if (hipGetDeviceProperties(&ctx->prop, device) != hipSuccess) { delete ctx; return C2D_ERR_NO_DEVICE; }
+    // The code object holds gfx950 kernels only: fail loudly anywhere else.
+    if (std::strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) { delete ctx; return C2D_ERR_NO_DEVICE; }
+    c2d::DeviceGuard g(device);
+    if (!g.ok) { delete ctx; return C2D_ERR_NO_DEVICE; }
+    if (hipMalloc(&ctx->d_counters, 64) != hipSuccess || hipMalloc(&ctx->d_bins, 32 * sizeof(float)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pinned), 64, hipHostMallocDefault) != hipSuccess) {
+        if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+        if (ctx->d_bins) (void)hipFree(ctx->d_bins);
+        delete ctx;
+        return C2D_ERR_NOMEM;
+    }
+    *out = ctx;
+    return C2D_OK;
+}
+
+int c2d_ctx_destroy(c2d_ctx* ctx)
+{
+    if (!ctx) return C2D_OK;
+    c2d::DeviceGuard g(ctx->device);
+    for (auto& p : ctx->d_list)
+        if (p) (void)hipFree(p);
+    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->d_bins) (void)hipFree(ctx->d_bins);
+    if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    delete ctx;
+    return C2D_OK;
+}
+
+int c2d_ctx_info(const c2d_ctx* ctx, c2d_device_info* out)
+{
+    if (!ctx || !out) return C2D_ERR_INVALID_ARG;
+    std::memset(out, 0, sizeof *out);
+    std::snprintf(out->name, sizeof out->name, "%s", ctx->prop.name);
+    std::snprintf(out->arch, sizeof out->arch, "%s", ctx->prop.gcnArchName);
+    out->device = ctx->device;
+    out->compute_units = ctx->prop.multiProcessorCount;
+    out->wavefront_size = ctx->prop.warpSize;
+    out->lds_bytes_per_cu = (int)ctx->prop.maxSharedMemoryPerMultiProcessor;
+    out->hbm_bytes = ctx->prop.totalGlobalMem;
+    return C2D_OK;
+}
+
+int c2d_malloc(c2d_ctx* ctx, void** d_ptr, size_t bytes)
+{
+    if (!ctx || !d_ptr) return C2D_ERR_INVALID_ARG;
+    *d_ptr = nullptr;
+    if (bytes == 0) return C2D_OK;
+    c2d::DeviceGuard g(ctx->device);
+    hipError_t e = hipMalloc(d_ptr, bytes);
+    if (e == hipErrorOutOfMemory) { ctx->last_error = "hipMalloc: out of memory"; return C2D_ERR_NOMEM; }
+    if (e != hipSuccess) return c2d::fail_hip(ctx, e, "hipMalloc", __FILE__, __LINE__);
+    return C2D_OK;
+}
+
+int c2d_free(c2d_ctx* ctx, void* d_ptr)
+{
+    if (!ctx) return C2D_ERR_INVALID_ARG;
+    if (!d_ptr) return C2D_OK;
+    c2d::DeviceGuard g(ctx->device);
+    C2D_HIP(ctx, hipFree(d_ptr));
+    return C2D_OK;
+}
+
+int c2d_memset(c2d_ctx* ctx, void* d_ptr, int value, size_t bytes, c2d_stream stream)
+{
+    if (!ctx || (!d_ptr && bytes)) return C2D_ERR_INVALID_ARG;
+    if (!bytes) return C2D_OK;
+    c2d::DeviceGuard g(ctx->device);
+    C2D_HIP(ctx, hipMemsetAsync(d_ptr, value, bytes, (hipStream_t)stream));
+    return C2D_OK;
+}
+
+int c2d_memcpy_h2d(c2d_ctx* ctx, void* d_dst, const void* h_src, size_t bytes, c2d_stream stream)
+{
+    if (!ctx || ((!d_dst || !h_src) && bytes)) return C2D_ERR_INVALID_ARG;
+    if (!bytes) return C2D_OK;
+    c2d::DeviceGuard g(ctx->device);
+    C2D_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return C2D_OK;
+}
+
+int c2d_memcpy_d2h(c2d_ctx* ctx, void* h_dst, const void* d_src, size_t bytes, c2d_stream stream)
+{
+    if (!ctx || ((!h_dst || !d_src) && bytes)) return C2D_ERR_INVALID_ARG;
+    if (!bytes) return C2D_OK;
+    c2d::DeviceGuard g(ctx->device);
+    C2D_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return C2D_OK;
+}
+
+int c2d_stream_create(c2d_ctx* ctx, c2d_stream* out)
+{
+    if (!ctx || !out) return C2D_ERR_INVALID_ARG;
+    c2d::DeviceGuard g(ctx->device);
+    hipStream_t s = nullptr;
+    C2D_HIP(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out = (c2d_stream)s;
+    return C2D_OK;
+}
+
+int c2d_stream_destroy(c2d_ctx* ctx, c2d_stream stream)
+{
+    if (!ctx) return C2D_ERR_INVALID_ARG;
+    if (!stream) return C2D_OK;
+    c2d::DeviceGuard g(ctx->device);
+    C2D_HIP(ctx, hipStreamDestroy((hipStream_t)stream));
+    return C2D_OK;
+}
+
+int c2d_stream_synchronize(c2d_ctx* ctx, c2d_stream stream)
+{
+    if (!ctx) return C2D_ERR_INVALID_ARG;
+    c2d::DeviceGuard g(ctx->device);
+    C2D_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return C2D_OK;
+}
+
+}  // extern "C"

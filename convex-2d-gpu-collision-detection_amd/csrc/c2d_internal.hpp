@@ -1,0 +1,77 @@
+// c2d_internal.hpp — context object and error plumbing shared by the C-ABI files.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/c2d.h"
+
+struct c2d_ctx {
+    int device = 0;
+    hipDeviceProp_t prop{};
+    // small device workspace owned by the ctx (adaptive MC bookkeeping)
+    uint32_t* d_list[2] = {nullptr, nullptr};  // active-scene index lists
+    size_t list_capacity = 0;
+    uint32_t* d_counters = nullptr;            // [0] next-active count
+    float* d_bins = nullptr;                   // accuracy_bins | bin_accuracy (<= 32 floats)
+    uint32_t* h_pinned = nullptr;              // pinned host word for count read-back
+    mutable std::string last_error;
+};
+
+namespace c2d {
+
+inline int fail_hip(const c2d_ctx* ctx, hipError_t e, const char* what, const char* file, int line)
+{
+    if (ctx) {
+        char buf[512];
+        std::snprintf(buf, sizeof buf, "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+        ctx->last_error = buf;
+    }
+    return C2D_ERR_HIP;
+}
+
+inline int fail_arg(const c2d_ctx* ctx, const char* msg)
+{
+    if (ctx) ctx->last_error = msg;
+    return C2D_ERR_INVALID_ARG;
+}
+
+#define C2D_HIP(ctx, call)                                                        \
+    do {                                                                          \
+        hipError_t e__ = (call);                                                  \
+        if (e__ != hipSuccess) return c2d::fail_hip(ctx, e__, #call, __FILE__, __LINE__); \
+    } while (0)
+
+// Launch-error check that does not synchronise (graph-capture safe).
+#define C2D_LAUNCH_CHECK(ctx)                                                     \
+    do {                                                                          \
+        hipError_t e__ = hipGetLastError();                                       \
+        if (e__ != hipSuccess) return c2d::fail_hip(ctx, e__, "kernel launch", __FILE__, __LINE__); \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+inline int grid_for(size_t work_items, int block, int max_blocks)
+{
+    size_t b = (work_items + (size_t)block - 1) / (size_t)block;
+    if (b < 1) b = 1;
+    if (b > (size_t)max_blocks) b = (size_t)max_blocks;
+    return (int)b;
+}
+
+}  // namespace c2d

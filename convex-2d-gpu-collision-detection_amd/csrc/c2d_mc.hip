@@ -1,0 +1,487 @@
+// c2d_mc.hip — Monte-Carlo collision probability on gfx950 (MI355X).
+//
+// Replaces monte_carlo_sample_collision_dataset_uniform
+// (reference compute_collision_probability.cu:90-150, generate_dataset.cu:175-253),
+// sample_rectangle (utils.cu:144-157), setup_kernel (utils.cu:111-117), the
+// thrust count/sort compaction (ccp.cu:307-319) and write_collision_probability
+// (utils.cu:210-215).
+//
+// Mapping.  The reference gives one thread one scene and runs its samples
+// serially.  Here one *wave* (64 lanes) owns one (scene, sample
+// chunk): the scene constants are wave-uniform (scalar registers), lane l
+// evaluates samples chunk_begin + l, + 64, ..., and hits are counted with
+// ballot + popcount in a scalar register.  The random stream is counter based
+// (Philox4x32-10 keyed by seed, scene, sample), so there is no RNG state in
+// memory, no set-up kernel, and any partition of the samples over waves, blocks
+// or GPUs gives the same hit count.  The kernel is VALU bound (~0 B of HBM
+// traffic per sample); see DESIGN.md for the per-sample op budget.
+#include "c2d_internal.hpp"
+#include "c2d_math.hpp"
+
+namespace c2d {
+
+constexpr int kMcBlock = 256;
+constexpr int kWavesPerBlock = kMcBlock / 64;
+
+// Wave-uniform description of one scene (reference ccp.cu:119-133).
+struct Scene {
+    float robot[8];       // robot rectangle in the obstacle frame
+    float hw, hh;         // obstacle half extents (create_rect: +-w/2, +-h/2)
+    float sx, sy, st, sw, sh;  // standard deviations (StdDev)
+};
+
+C2D_DEV Scene make_scene(float robot_w, float robot_h, float px, float py, const Pose& pose, const StdDev& sd)
+{
+    Scene sc;
+    float s, c;
+    sincos_(pose.theta, s, c);
+    rect_from_half_extents(robot_w / 2, robot_h / 2, c, s, px, py, sc.robot);  // ccp.cu:132-133
+    sc.hw = pose.width / 2;                                                    // ccp.cu:128
+    sc.hh = pose.height / 2;
+    sc.sx = sd.x; sc.sy = sd.y; sc.st = sd.theta; sc.sw = sd.width; sc.sh = sd.height;
+    return sc;
+}
+
+// The sampled obstacle of one sample (reference utils.cu:144-157).  The second
+// Philox block only feeds dh; it is skipped when sigma_h == 0 because dh = n*0
+// cannot change any vertex (the product is +-0 and is only ever added).
+C2D_DEV void sample_obstacle(const Scene& sc, uint64_t seed, uint64_t scene_id, uint64_t sample, float (&o)[8])
+{
+    const U4 a = philox_block(seed, scene_id, sample, 0);
+    float n0, n1, n2, n3;
+    box_muller(a.x, a.y, n0, n1);
+    box_muller(a.z, a.w, n2, n3);
+    const float dx = n0 * sc.sx, dy = n1 * sc.sy, dt = n2 * sc.st, dw = n3 * sc.sw;
+    float dh = 0.0f;
+    if (sc.sh != 0.0f) {  // wave-uniform
+        const U4 b = philox_block(seed, scene_id, sample, 1);
+        float n4, unused;
+        box_muller(b.x, b.y, n4, unused);
+        dh = n4 * sc.sh;
+    }
+    // r_out = r_in + create_rect(dw, dh): half extents add (utils.cu:152-155)
+    const float hx = sc.hw + dw / 2, hy = sc.hh + dh / 2;
+    float s, c;
+    sincos_(dt, s, c);
+    rect_from_half_extents(hx, hy, c, s, dx, dy, o);  // utils.cu:156
+}
+
+// convex_collide(robot, obstacle) (utils.cu:159-184).  All eight axes are part
+// of the result; the obstacle's four axes are skipped only when every lane of
+// the wave is already separated, which cannot change any lane's answer.
+C2D_DEV bool sample_collides(const Scene& sc, const float (&o)[8])
+{
+    bool sep = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float ax = sc.robot[(2 * i + 2) & 7] - sc.robot[2 * i];
+        float ay = sc.robot[(2 * i + 3) & 7] - sc.robot[2 * i + 1];
+        sep |= axis_separates(ax, ay, sc.robot, o);
+    }
+    if (__ballot(!sep) != 0ull) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float ax = o[(2 * i + 2) & 7] - o[2 * i];
+            float ay = o[(2 * i + 3) & 7] - o[2 * i + 1];
+            sep |= axis_separates(ax, ay, sc.robot, o);
+        }
+    }
+    return !sep;
+}
+
+// hits among samples [begin, begin + count) of one scene, computed by one wave
+C2D_DEV uint32_t wave_count_hits(const Scene& sc, uint64_t seed, uint64_t scene_id, uint64_t begin, uint32_t count)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t hits = 0;  // wave-uniform (scalar) accumulator
+    for (uint32_t off = 0; off < count; off += 64) {
+        const uint32_t idx = off + lane;
+        float o[8];
+        sample_obstacle(sc, seed, scene_id, begin + idx, o);
+        const bool hit = sample_collides(sc, o) && idx < count;
+        hits += (uint32_t)__popcll(__ballot(hit));
+    }
+    return hits;
+}
+
+// ---- one scene, sample-parallel (BASELINE config 3) -------------------------------
+struct PairArgs {
+    float robot_w, robot_h, px, py;
+    Pose pose;
+    StdDev sd;
+    uint64_t seed, scene_id, sample_begin, n_samples;
+    uint32_t chunk;  // samples per wave, multiple of 64
+};
+
+__global__ __launch_bounds__(kMcBlock) void mc_pair_kernel(PairArgs A, unsigned long long* __restrict__ d_hits)
+{
+    const Scene sc = make_scene(A.robot_w, A.robot_h, A.px, A.py, A.pose, A.sd);
+    const uint64_t n_chunks = (A.n_samples + A.chunk - 1) / A.chunk;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned long long total = 0;
+    for (uint64_t ch = (uint64_t)blockIdx.x * kWavesPerBlock + wave; ch < n_chunks; ch += (uint64_t)gridDim.x * kWavesPerBlock) {
+        const uint64_t off = ch * A.chunk;
+        const uint64_t left = A.n_samples - off;
+        const uint32_t count = left < A.chunk ? (uint32_t)left : A.chunk;
+        total += wave_count_hits(sc, A.seed, A.scene_id, A.sample_begin + off, count);
+    }
+    if ((threadIdx.x & 63) == 0 && total) atomicAdd(d_hits, total);
+}
+
+// ---- many scenes, adaptive (BASELINE config 4) --------------------------------------
+struct ScenesArgs {
+    const Pose* poses;
+    const StdDev* std_devs;
+    const PositionWithVarAndPoseIdx* scenes;
+    const uint32_t* active;   // indices of unfinished scenes, or NULL = identity
+    uint32_t n_active;
+    uint32_t num_poses, num_std_devs;
+    float robot_w, robot_h;
+    uint64_t seed, scene_id_base;
+    uint32_t n_start;         // samples already drawn for every active scene
+    uint32_t n_batch;         // samples to draw now
+    uint32_t waves_per_scene; // sample chunks per scene
+    uint32_t chunk;           // samples per chunk (multiple of 64)
+    uint32_t* hits;           // u32[n_scenes], accumulated
+};
+
+__global__ __launch_bounds__(kMcBlock) void mc_scenes_advance_kernel(ScenesArgs A)
+{
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t n_items = (uint64_t)A.n_active * A.waves_per_scene;
+    for (uint64_t item = (uint64_t)blockIdx.x * kWavesPerBlock + wave; item < n_items;
+         item += (uint64_t)gridDim.x * kWavesPerBlock) {
+        const uint32_t slot = (uint32_t)(item / A.waves_per_scene);
+        const uint32_t ch = (uint32_t)(item % A.waves_per_scene);
+        const uint32_t off = ch * A.chunk;
+        if (off >= A.n_batch) continue;
+        const uint32_t count = (A.n_batch - off) < A.chunk ? (A.n_batch - off) : A.chunk;
+        const uint32_t g = A.active ? A.active[slot] : slot;
+        const PositionWithVarAndPoseIdx row = A.scenes[g];
+        // float -> int index conversion as in ccp.cu:121-122; clamped so that a
+        // malformed row cannot read outside the tables
+        uint32_t pi = (uint32_t)(int)row.pose_idx, vi = (uint32_t)(int)row.var_idx;
+        pi = pi < A.num_poses ? pi : A.num_poses - 1;
+        vi = vi < A.num_std_devs ? vi : A.num_std_devs - 1;
+        const Pose pose = A.poses[pi];
+        const StdDev sd = A.std_devs[vi];
+        const Scene sc = make_scene(A.robot_w, A.robot_h, row.x, row.y, pose, sd);
+        const uint32_t h = wave_count_hits(sc, A.seed, A.scene_id_base + g, (uint64_t)A.n_start + off, count);
+        if ((threadIdx.x & 63) == 0 && h) atomicAdd(&A.hits[g], h);
+    }
+}
+
+// calcSlack (reference utils.cu:186-196), int overflow D1 fixed
+C2D_DEV float calc_slack(uint32_t n, uint32_t k)
+{
+    if (k == n || k == 0) {
+        // log(1.0 / (double)0.025f) / n, evaluated in double as in the reference
+        return (float)(0x1.d82d33932720dp+1 / (double)n);
+    }
+    const float z = 1.96f;
+    const float kf = (float)k;
+    const float kk = (float)((uint64_t)k * (uint64_t)k);
+    return z / (float)n * __builtin_sqrtf(kf - kk / (float)n);
+}
+
+// getBin (reference utils.cu:198-207), out-of-bounds read D2 fixed
+C2D_DEV int get_bin(float p, const float* bins, uint32_t n_bins)
+{
+    int bin = 0;
+    for (uint32_t i = 0; i + 1 < n_bins; i++)
+        if (p >= bins[i] && p <= bins[i + 1]) bin = (int)i;
+    return bin;
+}
+
+// After a batch: stop test of ccp.cu:140-148 per active scene, compaction of the
+// survivors into `next` (replaces thrust::count + sort_by_key, ccp.cu:307-311),
+// and write_collision_probability (utils.cu:210-215) for the finished ones.
+struct DecideArgs {
+    const PositionWithVarAndPoseIdx* scenes;
+    const uint32_t* active;
+    uint32_t n_active;
+    uint32_t n_samples;     // total drawn so far for the active scenes
+    uint32_t max_samples;
+    const float* bins;      // device: accuracy_bins[n_bins] then bin_accuracy[n_bins-1]
+    uint32_t n_bins;
+    const uint32_t* hits;
+    uint32_t* n_used;
+    PoseCPVarAndPoseIdx* rows;  // may be NULL
+    uint32_t* next;         // survivors
+    uint32_t* next_count;
+};
+
+__global__ __launch_bounds__(256) void mc_scenes_decide_kernel(DecideArgs A)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    bool survive = false;
+    uint32_t g = 0;
+    if (slot < A.n_active) {
+        g = A.active ? A.active[slot] : slot;
+        const uint32_t k = A.hits[g];
+        const uint32_t n = A.n_samples;
+        const float slack = calc_slack(n, k);
+        const float p = (float)k / (float)n;
+        const bool done = slack <= A.bins[A.n_bins + get_bin(p, A.bins, A.n_bins)];
+        if (done || n >= A.max_samples) {
+            A.n_used[g] = n;
+            if (A.rows) {
+                const PositionWithVarAndPoseIdx row = A.scenes[g];
+                PoseCPVarAndPoseIdx o;
+                o.x = row.x; o.y = row.y; o.cp = p; o.var_idx = row.var_idx; o.pose_idx = row.pose_idx;
+                A.rows[g] = o;
+            }
+        } else {
+            survive = true;
+        }
+    }
+    // wave-aggregated append: one atomic per wave
+    const unsigned long long m = __ballot(survive);
+    if (m) {
+        const uint32_t lane = threadIdx.x & 63;
+        uint32_t base = 0;
+        if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(A.next_count, (uint32_t)__popcll(m));
+        base = __shfl(base, __builtin_ctzll(m), 64);
+        if (survive) A.next[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = g;
+    }
+}
+
+// ---- RNG parity/debug kernel ----------------------------------------------------------
+__global__ void philox_normals_kernel(uint64_t seed, uint64_t scene_id, uint64_t sample_begin, size_t n,
+                                      float* __restrict__ normals, uint32_t* __restrict__ raw)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const U4 a = philox_block(seed, scene_id, sample_begin + i, 0);
+        const U4 b = philox_block(seed, scene_id, sample_begin + i, 1);
+        float v[6];
+        box_muller(a.x, a.y, v[0], v[1]);
+        box_muller(a.z, a.w, v[2], v[3]);
+        box_muller(b.x, b.y, v[4], v[5]);
+        for (int k = 0; k < 5; k++) normals[i * 5 + k] = v[k];
+        if (raw) {
+            raw[i * 8 + 0] = a.x; raw[i * 8 + 1] = a.y; raw[i * 8 + 2] = a.z; raw[i * 8 + 3] = a.w;
+            raw[i * 8 + 4] = b.x; raw[i * 8 + 5] = b.y; raw[i * 8 + 6] = b.z; raw[i * 8 + 7] = b.w;
+        }
+    }
+}
+
+// ---- scene sampler (reference generate_dataset.cu:207-219) ------------------------------
+constexpr uint64_t kSceneDomain = 0x5ce9e5a3c0117de5ull;
+
+__global__ void sample_scenes_kernel(const Pose* __restrict__ poses, uint32_t num_poses,
+                                     const StdDev* __restrict__ std_devs, uint32_t num_std_devs, float r_offset,
+                                     float spread, uint64_t seed, uint64_t scene_id_base, size_t n,
+                                     PositionWithVarAndPoseIdx* __restrict__ scenes)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += stride) {
+        const U4 a = philox_block(seed ^ kSceneDomain, scene_id_base + g, 0, 0);
+        const U4 b = philox_block(seed ^ kSceneDomain, scene_id_base + g, 0, 1);
+        const uint32_t pose_idx = a.x % num_poses;      // :208
+        const uint32_t sd_idx = a.y % num_std_devs;     // :209
+        const Pose pose = poses[pose_idx];
+        const StdDev sd = std_devs[sd_idx];
+        const float u = fma_((float)a.z, 0x1p-32f, 0x1p-33f);
+        const float theta = (float)((double)u * 2 * 3.14159265358979323846);  // :213
+        float nrm, unused;
+        box_muller(b.x, b.y, nrm, unused);
+        const float shift = nrm * ((sd.y + sd.x) / 2) * spread;               // :214
+        float st, ct;
+        sincos_(theta, st, ct);
+        const double bx = ((double)(pose.width / 2 + r_offset) + 2.35 + (double)sd.x) + (double)shift;   // :215
+        const double by = ((double)(pose.height / 2 + r_offset) + 2.35 + (double)sd.y) + (double)shift;  // :216
+        PositionWithVarAndPoseIdx row;
+        row.x = (float)((double)ct * bx);
+        row.y = (float)((double)st * by);
+        row.var_idx = (float)sd_idx;
+        row.pose_idx = (float)pose_idx;
+        scenes[g] = row;
+    }
+}
+
+}  // namespace c2d
+
+using namespace c2d;
+
+extern "C" {
+
+int c2d_philox_normals(c2d_ctx* ctx, uint64_t seed, uint64_t scene_id, uint64_t sample_begin, size_t n,
+                       float* d_normals, uint32_t* d_raw, c2d_stream stream)
+{
+    if (!ctx) return C2D_ERR_INVALID_ARG;
+    if (n == 0) return C2D_OK;
+    if (!d_normals) return fail_arg(ctx, "c2d_philox_normals: NULL output");
+    DeviceGuard g(ctx->device);
+    hipLaunchKernelGGL(philox_normals_kernel, dim3(grid_for(n, 256, ctx->prop.multiProcessorCount * 8)), dim3(256), 0,
+                       (hipStream_t)stream, seed, scene_id, sample_begin, n, d_normals, d_raw);
+    C2D_LAUNCH_CHECK(ctx);
+    return C2D_OK;
+}
+
+int c2d_mc_pair(c2d_ctx* ctx, float robot_w, float robot_h, const Position* pos, const Pose* pose,
+                const StdDev* std_dev, uint64_t seed, uint64_t scene_id, uint64_t sample_begin, uint64_t n_samples,
+                unsigned long long* d_hits, c2d_stream stream)
+{
+    if (!ctx) return C2D_ERR_INVALID_ARG;
+    if (!pos || !pose || !std_dev || !d_hits) return fail_arg(ctx, "c2d_mc_pair: NULL argument");
+    if (n_samples == 0) return C2D_OK;
+    if (sample_begin + n_samples < sample_begin || sample_begin + n_samples > (1ull << 62))
+        return fail_arg(ctx, "c2d_mc_pair: sample range overflows the 2^62-sample stream");
+    PairArgs A;
+    A.robot_w = robot_w; A.robot_h = robot_h; A.px = pos->x; A.py = pos->y;
+    A.pose = *pose; A.sd = *std_dev;
+    A.seed = seed; A.scene_id = scene_id; A.sample_begin = sample_begin; A.n_samples = n_samples;
+    // chunk: enough samples per wave to amortise scene set-up, enough waves to fill the chip
+    const uint64_t target_waves = (uint64_t)ctx->prop.multiProcessorCount * 32;
+    uint64_t chunk = (n_samples + target_waves - 1) / target_waves;
+    chunk = ((chunk + 63) / 64) * 64;
+    if (chunk < 64) chunk = 64;
+    if (chunk > 8192) chunk = 8192;
+    A.chunk = (uint32_t)chunk;
+    const uint64_t n_chunks = (n_samples + chunk - 1) / chunk;
+    uint64_t blocks = (n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
+    const uint64_t max_blocks = (uint64_t)ctx->prop.multiProcessorCount * 64;
+    if (blocks > max_blocks) blocks = max_blocks;
+    DeviceGuard g(ctx->device);
+    hipLaunchKernelGGL(mc_pair_kernel, dim3((unsigned)blocks), dim3(kMcBlock), 0, (hipStream_t)stream, A, d_hits);
+    C2D_LAUNCH_CHECK(ctx);
+    return C2D_OK;
+}
+
+static int ensure_lists(c2d_ctx* ctx, size_t n)
+{
+    if (ctx->list_capacity >= n) return C2D_OK;
+    for (auto& p : ctx->d_list) {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    }
+    ctx->list_capacity = 0;
+    for (auto& p : ctx->d_list) {
+        hipError_t e = hipMalloc(&p, n * sizeof(uint32_t));
+        if (e != hipSuccess) { ctx->last_error = "c2d_mc_scenes: workspace allocation failed"; return C2D_ERR_NOMEM; }
+    }
+    ctx->list_capacity = n;
+    return C2D_OK;
+}
+
+int c2d_mc_scenes(c2d_ctx* ctx, const c2d_mc_scenes_args* a, c2d_stream stream)
+{
+    if (!ctx) return C2D_ERR_INVALID_ARG;
+    if (!a) return fail_arg(ctx, "c2d_mc_scenes: NULL args");
+    if (a->total_samples) *a->total_samples = 0;
+    if (a->iterations) *a->iterations = 0;
+    if (a->n_scenes == 0) return C2D_OK;
+    if (!a->d_poses || !a->d_std_devs || !a->d_scenes || !a->d_hits || !a->d_n_used || !a->accuracy_bins || !a->bin_accuracy)
+        return fail_arg(ctx, "c2d_mc_scenes: NULL argument");
+    if (a->num_poses == 0 || a->num_std_devs == 0) return fail_arg(ctx, "c2d_mc_scenes: empty pose / std_dev table");
+    if (a->n_accuracy_bins < 2 || a->n_accuracy_bins > 16) return fail_arg(ctx, "c2d_mc_scenes: n_accuracy_bins must be 2..16");
+    if (a->n_scenes > 0xffffffffull) return fail_arg(ctx, "c2d_mc_scenes: more than 2^32-1 scenes in one call");
+    if (a->max_samples == 0 || a->max_samples > 0x7fffffffu - C2D_MC_LARGE_BATCH)
+        return fail_arg(ctx, "c2d_mc_scenes: max_samples out of range");
+    DeviceGuard g(ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    int st = ensure_lists(ctx, a->n_scenes);
+    if (st != C2D_OK) return st;
+
+    float h_bins[32];
+    for (uint32_t i = 0; i < a->n_accuracy_bins; i++) h_bins[i] = a->accuracy_bins[i];
+    for (uint32_t i = 0; i + 1 < a->n_accuracy_bins; i++) h_bins[a->n_accuracy_bins + i] = a->bin_accuracy[i];
+    C2D_HIP(ctx, hipMemcpyAsync(ctx->d_bins, h_bins, (2 * a->n_accuracy_bins - 1) * sizeof(float), hipMemcpyHostToDevice, s));
+    C2D_HIP(ctx, hipStreamSynchronize(s));  // h_bins is a stack buffer
+    C2D_HIP(ctx, hipMemsetAsync(a->d_hits, 0, a->n_scenes * sizeof(uint32_t), s));
+
+    const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
+    uint32_t n_active = (uint32_t)a->n_scenes;
+    uint32_t n_samples = 0, iter = 0;
+    uint64_t total = 0;
+    const uint32_t* cur = nullptr;  // identity on the first step
+    int flip = 0;
+    while (n_active > 0 && n_samples < a->max_samples) {  // ccp.cu:281
+        const uint32_t n_batch = n_samples < C2D_MC_SWITCH_AT ? C2D_MC_SMALL_BATCH : C2D_MC_LARGE_BATCH;  // ccp.cu:283-286
+        ScenesArgs A;
+        A.poses = a->d_poses; A.std_devs = a->d_std_devs; A.scenes = a->d_scenes;
+        A.active = cur; A.n_active = n_active;
+        A.num_poses = a->num_poses; A.num_std_devs = a->num_std_devs;
+        A.robot_w = a->robot_w; A.robot_h = a->robot_h;
+        A.seed = a->seed; A.scene_id_base = a->scene_id_base;
+        A.n_start = n_samples; A.n_batch = n_batch;
+        // split a scene's batch over several waves when few scenes are left, so
+        // that the tail of the adaptive loop still fills the chip
+        const uint32_t max_split = (n_batch + 63) / 64;
+        const uint64_t want_waves = (uint64_t)cus * 32;
+        uint32_t wps = (uint32_t)((want_waves + n_active - 1) / n_active);
+        if (wps < 1) wps = 1;
+        if (wps > max_split) wps = max_split;
+        uint32_t chunk = (n_batch + wps - 1) / wps;
+        chunk = ((chunk + 63) / 64) * 64;
+        wps = (n_batch + chunk - 1) / chunk;
+        A.waves_per_scene = wps; A.chunk = chunk;
+        A.hits = a->d_hits;
+        const uint64_t items = (uint64_t)n_active * wps;
+        uint64_t blocks = (items + kWavesPerBlock - 1) / kWavesPerBlock;
+        const uint64_t max_blocks = (uint64_t)cus * 64;
+        if (blocks > max_blocks) blocks = max_blocks;
+        hipLaunchKernelGGL(mc_scenes_advance_kernel, dim3((unsigned)blocks), dim3(kMcBlock), 0, s, A);
+        C2D_LAUNCH_CHECK(ctx);
+        n_samples += n_batch;
+        total += (uint64_t)n_active * n_batch;
+
+        C2D_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(uint32_t), s));
+        DecideArgs D;
+        D.scenes = a->d_scenes; D.active = cur; D.n_active = n_active;
+        D.n_samples = n_samples; D.max_samples = a->max_samples;
+        D.bins = ctx->d_bins; D.n_bins = a->n_accuracy_bins;
+        D.hits = a->d_hits; D.n_used = a->d_n_used; D.rows = a->d_rows;
+        D.next = ctx->d_list[flip]; D.next_count = ctx->d_counters;
+        hipLaunchKernelGGL(mc_scenes_decide_kernel, dim3((n_active + 255) / 256), dim3(256), 0, s, D);
+        C2D_LAUNCH_CHECK(ctx);
+        C2D_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, ctx->d_counters, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        C2D_HIP(ctx, hipStreamSynchronize(s));
+        n_active = ctx->h_pinned[0];
+        cur = ctx->d_list[flip];
+        flip ^= 1;
+        iter++;
+    }
+    if (a->total_samples) *a->total_samples = total;
+    if (a->iterations) *a->iterations = iter;
+    return C2D_OK;
+}
+
+int c2d_sample_scenes(c2d_ctx* ctx, const Pose* d_poses, uint32_t num_poses, const StdDev* d_std_devs,
+                      uint32_t num_std_devs, float robot_w, float robot_h, float spread, uint64_t seed,
+                      uint64_t scene_id_base, size_t n_scenes, PositionWithVarAndPoseIdx* d_scenes, c2d_stream stream)
+{
+    if (!ctx) return C2D_ERR_INVALID_ARG;
+    if (n_scenes == 0) return C2D_OK;
+    if (!d_poses || !d_std_devs || !d_scenes || num_poses == 0 || num_std_devs == 0)
+        return fail_arg(ctx, "c2d_sample_scenes: NULL / empty argument");
+    DeviceGuard g(ctx->device);
+    const float r_offset = (robot_w + robot_h) / 4;  // generate_dataset.cu:398
+    hipLaunchKernelGGL(sample_scenes_kernel, dim3(grid_for(n_scenes, 256, ctx->prop.multiProcessorCount * 8)), dim3(256), 0,
+                       (hipStream_t)stream, d_poses, num_poses, d_std_devs, num_std_devs, r_offset, spread, seed,
+                       scene_id_base, n_scenes, d_scenes);
+    C2D_LAUNCH_CHECK(ctx);
+    return C2D_OK;
+}
+
+// Host mirrors of the stopping statistics (same expressions as the device code).
+float c2d_calc_slack(uint32_t n, uint32_t k)
+{
+    if (k == n || k == 0) return (float)(0x1.d82d33932720dp+1 / (double)n);
+    const float z = 1.96f;
+    const float kf = (float)k;
+    const float kk = (float)((uint64_t)k * (uint64_t)k);
+    return z / (float)n * __builtin_sqrtf(kf - kk / (float)n);
+}
+
+int c2d_get_bin(float p, const float* accuracy_bins, uint32_t n_accuracy_bins)
+{
+    int bin = 0;
+    if (!accuracy_bins) return 0;
+    for (uint32_t i = 0; i + 1 < n_accuracy_bins; i++)
+        if (p >= accuracy_bins[i] && p <= accuracy_bins[i + 1]) bin = (int)i;
+    return bin;
+}
+
+}  // extern "C"

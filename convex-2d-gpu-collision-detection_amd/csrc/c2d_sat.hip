@@ -1,0 +1,334 @@
+// c2d_sat.hip — batched SAT kernels for gfx950 (MI355X).
+//
+// Hot path of BASELINE config 2: the arithmetic of convex_collide (reference
+// utils.cu:159-184) over n independent rectangle pairs held as 16 SoA planes.
+// The kernel is HBM-bound: 16 x 4 B read + 1 B written per pair (65 B/pair,
+// ~300 VALU ops/pair).  Mapping: one lane owns VEC consecutive pairs, loads
+// them with one global_load_dwordx4 per plane (1 KiB per wave instruction,
+// 16 independent loads in flight per lane), keeps everything in VGPRs (no LDS:
+// a rectangle pair has no reuse across lanes), and writes VEC result bytes
+// with one store.  The count of colliding pairs is reduced per wave with
+// ballot/popcount and leaves the block as a single 64-bit atomic.
+#include "c2d_internal.hpp"
+#include "c2d_math.hpp"
+
+namespace c2d {
+
+struct Planes16 { const float* p[16]; };
+struct Planes10 { const float* p[10]; };
+struct Planes8 { float* p[8]; };
+
+constexpr int kBlock = 256;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Block-level sum of per-lane counts -> one atomic.  Wave sums go through
+// DPP-free shuffles (64-wide), wave leaders through LDS.
+C2D_DEV void block_count_atomic(uint32_t lane_count, unsigned long long* d_count)
+{
+    __shared__ uint32_t wave_sums[kBlock / 64];
+    uint32_t v = lane_count;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_sums[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t s = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; w++) s += wave_sums[w];
+        if (s) atomicAdd(d_count, (unsigned long long)s);
+    }
+}
+
+// ---- rectangle pairs, vertex format ------------------------------------------
+// VEC == 4: planes read as float4 (16 B / lane), results written as one dword.
+// VEC == 1: scalar loads; used for the tail and for unaligned buffers.
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void sat_rect_verts_kernel(Planes16 P, size_t first, size_t n_groups,
+                                                                uint8_t* __restrict__ out,
+                                                                unsigned long long* __restrict__ d_count)
+{
+    uint32_t my_count = 0;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x; g < n_groups; g += stride) {
+        if constexpr (VEC == 4) {
+            f32x4 v[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P.p[k]) + g);
+            uint32_t packed = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float r1[8], r2[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    r1[k] = v[k][e];
+                    r2[k] = v[8 + k][e];
+                }
+                uint32_t c = rect_collide(r1, r2) ? 1u : 0u;
+                packed |= c << (8 * e);
+                my_count += c;
+            }
+            __builtin_nontemporal_store(packed, reinterpret_cast<uint32_t*>(out) + g);
+        } else {
+            const size_t i = first + g;
+            float r1[8], r2[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                r1[k] = P.p[k][i];
+                r2[k] = P.p[8 + k][i];
+            }
+            uint32_t c = rect_collide(r1, r2) ? 1u : 0u;
+            out[i] = (uint8_t)c;
+            my_count += c;
+        }
+    }
+    if (d_count) block_count_atomic(my_count, d_count);
+}
+
+// ---- rectangle pairs, pose format (10 planes) -----------------------------------
+__global__ __launch_bounds__(kBlock) void sat_rect_pose_kernel(Planes10 P, size_t n, uint8_t* __restrict__ out,
+                                                               unsigned long long* __restrict__ d_count)
+{
+    uint32_t my_count = 0;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        float v[10];
+#pragma unroll
+        for (int k = 0; k < 10; k++) v[k] = P.p[k][i];
+        float r1[8], r2[8], s, c;
+        sincos_(v[4], s, c);
+        rect_from_half_extents(v[2] / 2, v[3] / 2, c, s, v[0], v[1], r1);
+        sincos_(v[9], s, c);
+        rect_from_half_extents(v[7] / 2, v[8] / 2, c, s, v[5], v[6], r2);
+        uint32_t hit = rect_collide(r1, r2) ? 1u : 0u;
+        out[i] = (uint8_t)hit;
+        my_count += hit;
+    }
+    if (d_count) block_count_atomic(my_count, d_count);
+}
+
+// ---- create_rect + rot_trans_rectangle over SoA (reference utils.cu:119-142) ------
+__global__ __launch_bounds__(kBlock) void rects_from_poses_kernel(const float* __restrict__ cx, const float* __restrict__ cy,
+                                                                  const float* __restrict__ w, const float* __restrict__ h,
+                                                                  const float* __restrict__ th, size_t n, Planes8 O)
+{
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        float r[8], s, c;
+        sincos_(th[i], s, c);
+        rect_from_half_extents(w[i] / 2, h[i] / 2, c, s, cx[i], cy[i], r);
+#pragma unroll
+        for (int k = 0; k < 8; k++) O.p[k][i] = r[k];
+    }
+}
+
+// ---- convex polygons, K <= 16, true normals ----------------------------------------
+// Work split: 32 lanes per pair, lane a owns axis a (edge a of polygon A for
+// a < ka, edge a-ka of polygon B otherwise), so all ka+kb axes of a pair are
+// evaluated side by side and the "found a separating axis" decision is one
+// ballot.  Vertices are staged in LDS by the whole block with coalesced loads
+// (pair index fastest in memory), then every lane walks the pair's vertex list
+// with broadcast LDS reads.  A block handles kPolyPairs pairs per pass.
+constexpr int kPolyPairs = 64;                  // pairs staged per block pass
+constexpr int kPolyStride = 2 * C2D_POLY_KMAX;  // vertices per pair slot (A then B)
+
+__global__ __launch_bounds__(kBlock) void sat_poly_kernel(const float* __restrict__ vx, const float* __restrict__ vy,
+                                                          const uint8_t* __restrict__ kcnt, size_t n,
+                                                          uint8_t* __restrict__ out,
+                                                          unsigned long long* __restrict__ d_count)
+{
+    // [pair][vertex] as float2; +1 float2 of padding per pair slot keeps the two
+    // half-waves (two different pairs) on different banks for the broadcast reads.
+    __shared__ float2 s_v[kPolyPairs][kPolyStride + 1];
+    __shared__ uint8_t s_k[2][kPolyPairs];
+    uint32_t my_count = 0;
+    const int tid = threadIdx.x;
+    const int half = tid >> 5;   // 0..7: which pair of the current group of 8
+    const int a = tid & 31;      // axis owned by this lane
+    const size_t n_pass = (n + kPolyPairs - 1) / kPolyPairs;
+    for (size_t pass = blockIdx.x; pass < n_pass; pass += gridDim.x) {
+        const size_t base = pass * kPolyPairs;
+        const int pairs_here = (int)((n - base) < (size_t)kPolyPairs ? (n - base) : (size_t)kPolyPairs);
+        __syncthreads();  // previous pass finished reading LDS
+        if (tid < 2 * kPolyPairs) {
+            int p = tid / kPolyPairs, j = tid % kPolyPairs;
+            s_k[p][j] = j < pairs_here ? kcnt[(size_t)p * n + base + j] : (uint8_t)0;
+        }
+        __syncthreads();
+        // stage: thread t loads pair j = t % 64 for rows (p,v) = t/64, t/64+4, ...
+        {
+            const int j = tid & (kPolyPairs - 1);
+            for (int row = tid / kPolyPairs; row < kPolyStride; row += kBlock / kPolyPairs) {
+                const int p = row / C2D_POLY_KMAX, v = row % C2D_POLY_KMAX;
+                float2 val = make_float2(0.f, 0.f);
+                if (j < pairs_here && v < (int)s_k[p][j]) {
+                    const size_t idx = ((size_t)p * C2D_POLY_KMAX + v) * n + base + j;
+                    val.x = vx[idx];
+                    val.y = vy[idx];
+                }
+                s_v[j][row] = val;
+            }
+        }
+        __syncthreads();
+        // evaluate: 8 pairs at a time (one per half-wave)
+        for (int j0 = 0; j0 < pairs_here; j0 += kBlock / 32) {
+            const int j = j0 + half;
+            const bool live = j < pairs_here;
+            const int ka = live ? (int)s_k[0][j] : 0, kb = live ? (int)s_k[1][j] : 0;
+            bool sep = false;
+            if (a < ka + kb) {
+                const float2* A = &s_v[j][0];
+                const float2* B = &s_v[j][C2D_POLY_KMAX];
+                const bool onA = a < ka;
+                const float2* Pn = onA ? A : B;
+                const int kp = onA ? ka : kb;
+                const int i = onA ? a : a - ka;
+                const int i1 = (i + 1 == kp) ? 0 : i + 1;
+                const float2 e0 = Pn[i], e1 = Pn[i1];
+                const float ex = e1.x - e0.x, ey = e1.y - e0.y;
+                const float nx = -ey, ny = ex;
+                float min1, max1, min2, max2;
+                {
+                    float2 q = A[0];
+                    min1 = max1 = nx * q.x + ny * q.y;
+                    for (int k = 1; k < ka; k++) {
+                        q = A[k];
+                        float p = nx * q.x + ny * q.y;
+                        min1 = p < min1 ? p : min1;
+                        max1 = max1 < p ? p : max1;
+                    }
+                    q = B[0];
+                    min2 = max2 = nx * q.x + ny * q.y;
+                    for (int k = 1; k < kb; k++) {
+                        q = B[k];
+                        float p = nx * q.x + ny * q.y;
+                        min2 = p < min2 ? p : min2;
+                        max2 = max2 < p ? p : max2;
+                    }
+                }
+                sep = (max1 < min2) || (max2 < min1);
+            }
+            const unsigned long long ballot = __ballot(sep);
+            const uint32_t mine = (uint32_t)(ballot >> (32 * (half & 1)));
+            if (a == 0 && live) {
+                const uint32_t c = mine == 0 ? 1u : 0u;
+                out[base + j] = (uint8_t)c;
+                my_count += c;
+            }
+        }
+    }
+    if (d_count) block_count_atomic(my_count, d_count);
+}
+
+__global__ void poly_validate_kernel(const uint8_t* __restrict__ kcnt, size_t n2, uint32_t* __restrict__ bad)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    uint32_t b = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        uint8_t k = kcnt[i];
+        b |= (k < 1 || k > C2D_POLY_KMAX) ? 1u : 0u;
+    }
+    if (b) atomicOr(bad, 1u);
+}
+
+static inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+}  // namespace c2d
+
+using namespace c2d;
+
+extern "C" {
+
+int c2d_rects_from_poses(c2d_ctx* ctx, const float* d_cx, const float* d_cy, const float* d_w, const float* d_h,
+                         const float* d_theta, size_t n, float* const d_out_planes[8], c2d_stream stream)
+{
+    if (!ctx) return C2D_ERR_INVALID_ARG;
+    if (n == 0) return C2D_OK;
+    if (!d_cx || !d_cy || !d_w || !d_h || !d_theta || !d_out_planes) return fail_arg(ctx, "c2d_rects_from_poses: NULL plane");
+    Planes8 O;
+    for (int k = 0; k < 8; k++) {
+        if (!d_out_planes[k]) return fail_arg(ctx, "c2d_rects_from_poses: NULL output plane");
+        O.p[k] = d_out_planes[k];
+    }
+    DeviceGuard g(ctx->device);
+    const int grid = grid_for(n, kBlock, ctx->prop.multiProcessorCount * 8);
+    hipLaunchKernelGGL(rects_from_poses_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, d_cx, d_cy, d_w, d_h,
+                       d_theta, n, O);
+    C2D_LAUNCH_CHECK(ctx);
+    return C2D_OK;
+}
+
+int c2d_sat_rect_pairs_verts(c2d_ctx* ctx, const float* const d_planes[16], size_t n, uint8_t* d_out,
+                             unsigned long long* d_count, c2d_stream stream)
+{
+    if (!ctx) return C2D_ERR_INVALID_ARG;
+    if (n == 0) return C2D_OK;
+    if (!d_planes || !d_out) return fail_arg(ctx, "c2d_sat_rect_pairs_verts: NULL argument");
+    Planes16 P;
+    bool wide = aligned_to(d_out, 4);
+    for (int k = 0; k < 16; k++) {
+        if (!d_planes[k]) return fail_arg(ctx, "c2d_sat_rect_pairs_verts: NULL plane");
+        P.p[k] = d_planes[k];
+        wide = wide && aligned_to(d_planes[k], 16);
+    }
+    DeviceGuard g(ctx->device);
+    const int max_blocks = ctx->prop.multiProcessorCount * 8;
+    const size_t n4 = wide ? n / 4 : 0;
+    if (n4) {
+        const int grid = grid_for(n4, kBlock, max_blocks);
+        hipLaunchKernelGGL(sat_rect_verts_kernel<4>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, P, (size_t)0, n4,
+                           d_out, d_count);
+        C2D_LAUNCH_CHECK(ctx);
+    }
+    const size_t rest = n - 4 * n4;
+    if (rest) {
+        const int grid = grid_for(rest, kBlock, max_blocks);
+        hipLaunchKernelGGL(sat_rect_verts_kernel<1>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, P, 4 * n4, rest,
+                           d_out, d_count);
+        C2D_LAUNCH_CHECK(ctx);
+    }
+    return C2D_OK;
+}
+
+int c2d_sat_rect_pairs_pose(c2d_ctx* ctx, const float* const d_pose_planes[10], size_t n, uint8_t* d_out,
+                            unsigned long long* d_count, c2d_stream stream)
+{
+    if (!ctx) return C2D_ERR_INVALID_ARG;
+    if (n == 0) return C2D_OK;
+    if (!d_pose_planes || !d_out) return fail_arg(ctx, "c2d_sat_rect_pairs_pose: NULL argument");
+    Planes10 P;
+    for (int k = 0; k < 10; k++) {
+        if (!d_pose_planes[k]) return fail_arg(ctx, "c2d_sat_rect_pairs_pose: NULL plane");
+        P.p[k] = d_pose_planes[k];
+    }
+    DeviceGuard g(ctx->device);
+    const int grid = grid_for(n, kBlock, ctx->prop.multiProcessorCount * 8);
+    hipLaunchKernelGGL(sat_rect_pose_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, P, n, d_out, d_count);
+    C2D_LAUNCH_CHECK(ctx);
+    return C2D_OK;
+}
+
+int c2d_sat_poly_pairs(c2d_ctx* ctx, const float* d_vx, const float* d_vy, const uint8_t* d_k, size_t n,
+                       uint8_t* d_out, unsigned long long* d_count, c2d_stream stream)
+{
+    if (!ctx) return C2D_ERR_INVALID_ARG;
+    if (n == 0) return C2D_OK;
+    if (!d_vx || !d_vy || !d_k || !d_out) return fail_arg(ctx, "c2d_sat_poly_pairs: NULL argument");
+    DeviceGuard g(ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    // vertex counts outside 1..KMAX would index past a pair's LDS slot: reject them up front
+    C2D_HIP(ctx, hipMemsetAsync(ctx->d_counters + 8, 0, sizeof(uint32_t), s));
+    hipLaunchKernelGGL(poly_validate_kernel, dim3(grid_for(2 * n, 256, ctx->prop.multiProcessorCount * 4)), dim3(256), 0, s,
+                       d_k, 2 * n, ctx->d_counters + 8);
+    C2D_LAUNCH_CHECK(ctx);
+    C2D_HIP(ctx, hipMemcpyAsync(ctx->h_pinned + 8, ctx->d_counters + 8, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    C2D_HIP(ctx, hipStreamSynchronize(s));
+    if (ctx->h_pinned[8]) return fail_arg(ctx, "c2d_sat_poly_pairs: vertex count outside 1..C2D_POLY_KMAX");
+    const size_t n_pass = (n + kPolyPairs - 1) / kPolyPairs;
+    const int grid = (int)(n_pass < (size_t)ctx->prop.multiProcessorCount * 8 ? n_pass : (size_t)ctx->prop.multiProcessorCount * 8);
+    hipLaunchKernelGGL(sat_poly_kernel, dim3(grid), dim3(kBlock), 0, s, d_vx, d_vy, d_k, n, d_out, d_count);
+    C2D_LAUNCH_CHECK(ctx);
+    return C2D_OK;
+}
+
+}  // extern "C"

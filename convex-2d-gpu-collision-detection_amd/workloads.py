@@ -1,0 +1,91 @@
+"""Synthetic inputs for the BASELINE.json configurations (host-side numpy only).
+
+Shapes and ranges follow SURVEY.md §8(d): rectangle sizes are drawn from the
+reference's default pose range min_pose/max_pose = [0.1, 5] (generate_dataset.cu:56-57),
+centres from U(-8, 8), angles from U(0, 2*pi).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+KMAX = 16
+
+# BASELINE config 3: one fixed robot + one Gaussian-pose obstacle
+# (robot size = reference defaults, compute_collision_probability.cu:39-40).
+MC_PAIR_SCENE = {
+    "robot_w": 4.07, "robot_h": 1.74,
+    "pos": (3.0, 1.0),
+    "pose": (2.0, 1.0, 0.6),                  # width, height, theta
+    "std_dev": (0.3, 0.3, 0.2, 0.0, 0.0),     # x, y, theta, width, height
+}
+
+DEFAULT_BINS = (0.0, 0.01, 0.1, 1.0)          # generate_dataset.cu:58
+DEFAULT_BIN_ACCURACY = (1e-4, 1e-3, 1e-2)     # generate_dataset.cu:59
+
+
+def random_obb_pose_planes(n: int, seed: int = 0x5A7, extent: float = 8.0) -> np.ndarray:
+    """float32 [10][n]: (cx, cy, w, h, theta) of rectangle 1 then rectangle 2."""
+    rng = np.random.Generator(np.random.Philox(seed))
+    out = np.empty((10, n), np.float32)
+    for r in range(2):
+        out[5 * r + 0] = rng.uniform(-extent, extent, n)
+        out[5 * r + 1] = rng.uniform(-extent, extent, n)
+        out[5 * r + 2] = rng.uniform(0.1, 5.0, n)
+        out[5 * r + 3] = rng.uniform(0.1, 5.0, n)
+        out[5 * r + 4] = rng.uniform(0.0, 2.0 * np.pi, n)
+    return out
+
+
+def random_convex_polygons(n: int, seed: int = 0xC0FFEE, kmin: int = 3, kmax: int = KMAX, extent: float = 8.0):
+    """BASELINE config 5 input: vx, vy float32 [2][KMAX][n], k uint8 [2][n].
+    Each polygon has K ~ U{kmin..kmax} vertices at sorted random angles on an
+    ellipse (hence convex, counter-clockwise), randomly rotated and placed."""
+    rng = np.random.Generator(np.random.Philox(seed))
+    vx = np.zeros((2, KMAX, n), np.float32)
+    vy = np.zeros((2, KMAX, n), np.float32)
+    k = rng.integers(kmin, kmax + 1, size=(2, n)).astype(np.uint8)
+    for p in range(2):
+        mask = np.arange(KMAX)[:, None] >= k[p][None, :]
+        ang = rng.uniform(0.0, 2.0 * np.pi, size=(KMAX, n))
+        ang[mask] = np.inf                      # unused slots sort to the end
+        ang = np.sort(ang, axis=0)              # the K used angles ascend: counter-clockwise
+        ang[mask] = 0.0
+        a = rng.uniform(0.3, 2.5, n)
+        b = rng.uniform(0.3, 2.5, n)
+        rot = rng.uniform(0.0, 2.0 * np.pi, n)
+        cx = rng.uniform(-extent, extent, n)
+        cy = rng.uniform(-extent, extent, n)
+        x = a[None, :] * np.cos(ang)
+        y = b[None, :] * np.sin(ang)
+        c, s = np.cos(rot)[None, :], np.sin(rot)[None, :]
+        vx[p] = (c * x - s * y + cx[None, :]).astype(np.float32)
+        vy[p] = (s * x + c * y + cy[None, :]).astype(np.float32)
+        vx[p][mask] = 0.0
+        vy[p][mask] = 0.0
+    return vx, vy, k
+
+
+def random_tables(num_poses: int, num_variances: int, seed: int = 7, shape_variance: bool = False):
+    """Pose and StdDev tables as generate_dataset builds them (generate_dataset.cu:282-332):
+    variances ~ U(0, 0.3) per dimension (width/height forced to 0 unless
+    shape_variance), std_dev = sqrt(variance); poses ~ U([0.1,0.1,0],[5,5,2pi])."""
+    from .binding import POSE_DT, STD_DT
+
+    rng = np.random.Generator(np.random.Philox(seed))
+    var = rng.uniform(0.0, 0.3, size=(num_variances, 5)).astype(np.float32)
+    if not shape_variance:
+        var[:, 3:] = 0.0
+    sd = np.sqrt(var).astype(np.float32)
+    poses = np.empty((num_poses, 3), np.float32)
+    poses[:, 0] = rng.uniform(0.1, 5.0, num_poses)
+    poses[:, 1] = rng.uniform(0.1, 5.0, num_poses)
+    poses[:, 2] = rng.uniform(0.0, 2.0 * np.pi, num_poses)
+    return poses.view(POSE_DT).reshape(-1), sd.view(STD_DT).reshape(-1), var
+
+
+def shard_range(total: int, rank: int, world: int):
+    """Contiguous range partition [begin, end) of `total` units for `rank` of `world`
+    (SURVEY.md §8e): the first total % world ranks get one extra unit."""
+    base, rem = divmod(total, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)

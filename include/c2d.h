@@ -1,0 +1,229 @@
+/*
+ * c2d.h — C-ABI of the MI355X-native batched 2D SAT collision engine (libc2d.so).
+ *
+ * This is the drop-in boundary of the hot path.  The reference exposes no FFI
+ * (SURVEY.md §8b): its boundary is the set of __device__/__global__ functions in
+ * utils.cu plus the host loops in the three main()s.  Every entry point below
+ * names the reference interface it replaces (file:line under /root/reference).
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes, no C++/torch types;
+ *   - return an int status (C2D_OK == 0, negative on error), never exit();
+ *     the reference prints and exit()s (utils.cu:59-72);
+ *   - buffers are caller-owned; pointers named d_* / "device" are HIP device
+ *     pointers on the context's device, everything else is host memory;
+ *   - work is enqueued on the caller's stream (a hipStream_t passed as void*,
+ *     NULL = the default stream) and is asynchronous unless stated otherwise;
+ *   - a c2d_ctx is bound to one device; use one ctx per device / per host thread.
+ *
+ * Arithmetic contract (DESIGN.md §"Canonical arithmetic"): IEEE binary32,
+ * round-to-nearest-even, no multiply-add contraction except where the spec
+ * says fma; sin/cos/log are the c2d polynomial forms (bit-reproducible on any
+ * IEEE machine), sqrt and divide are correctly rounded.  Booleans and hit
+ * counts are therefore bit-exact against the CPU oracle in oracle/.
+ */
+#ifndef C2D_H_
+#define C2D_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "utils.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define C2D_VERSION_MAJOR 0
+#define C2D_VERSION_MINOR 1
+
+/* ---- status codes ------------------------------------------------------ */
+#define C2D_OK 0
+#define C2D_ERR_INVALID_ARG (-1)  /* NULL pointer, bad size, bad vertex count ...        */
+#define C2D_ERR_HIP (-2)          /* a HIP runtime call failed; see c2d_last_error()     */
+#define C2D_ERR_NO_DEVICE (-3)    /* no usable gfx950 device / device index out of range */
+#define C2D_ERR_NOMEM (-4)        /* device or host allocation failed                    */
+#define C2D_ERR_UNSUPPORTED (-5)  /* argument combination outside the documented domain  */
+
+typedef struct c2d_ctx c2d_ctx;
+typedef void* c2d_stream; /* hipStream_t */
+
+/* Fixed sampling schedule of the adaptive Monte-Carlo loop
+ * (reference compute_collision_probability.cu:283-287, generate_dataset.cu:427-431):
+ * batches of 1000 samples while n_samples < 20000, then batches of 100000. */
+#define C2D_MC_SMALL_BATCH 1000
+#define C2D_MC_LARGE_BATCH 100000
+#define C2D_MC_SWITCH_AT 20000
+
+typedef struct c2d_device_info {
+    char name[128];
+    char arch[64];
+    int device;
+    int compute_units;
+    int wavefront_size;
+    int lds_bytes_per_cu;
+    size_t hbm_bytes;
+} c2d_device_info;
+
+/* ---- library / context --------------------------------------------------- */
+int c2d_version(void); /* MAJOR*1000 + MINOR */
+const char* c2d_status_string(int status);
+/* Last error text of this ctx (HIP error string and call site); "" if none. */
+const char* c2d_last_error(const c2d_ctx* ctx);
+int c2d_device_count(int* count);
+/* Replaces the implicit device-0 + default-stream set-up of the reference mains
+ * (compute_collision_probability.cu:212-251). */
+int c2d_ctx_create(int device, c2d_ctx** out);
+int c2d_ctx_destroy(c2d_ctx* ctx);
+int c2d_ctx_info(const c2d_ctx* ctx, c2d_device_info* out);
+
+/* ---- memory / stream plumbing ---------------------------------------------
+ * Replace cudaMalloc / cudaMemcpy / cudaFree / cudaDeviceSynchronize in the
+ * reference mains (compute_collision_probability.cu:212-248, :314-334, :367-377;
+ * generate_dataset.cu:371-405, :461-482, :512-522).  Copies are asynchronous
+ * on `stream`; call c2d_stream_synchronize before touching the host buffer. */
+int c2d_malloc(c2d_ctx* ctx, void** d_ptr, size_t bytes);
+int c2d_free(c2d_ctx* ctx, void* d_ptr);
+int c2d_memset(c2d_ctx* ctx, void* d_ptr, int value, size_t bytes, c2d_stream stream);
+int c2d_memcpy_h2d(c2d_ctx* ctx, void* d_dst, const void* h_src, size_t bytes, c2d_stream stream);
+int c2d_memcpy_d2h(c2d_ctx* ctx, void* h_dst, const void* d_src, size_t bytes, c2d_stream stream);
+int c2d_stream_create(c2d_ctx* ctx, c2d_stream* out);
+int c2d_stream_destroy(c2d_ctx* ctx, c2d_stream stream);
+int c2d_stream_synchronize(c2d_ctx* ctx, c2d_stream stream);
+
+/* ---- geometry ---------------------------------------------------------------
+ *
+ * c2d_rects_from_poses: batched create_rect (utils.cu:119-130) followed by
+ * rot_trans_rectangle (utils.cu:132-142): rectangle i has size w[i] x h[i],
+ * is rotated by theta[i] about its centre and translated to (cx[i], cy[i]).
+ * Inputs are 5 device planes f32[n]; output is 8 device planes f32[n] in the
+ * reference's flat order x0,y0,x1,y1,x2,y2,x3,y3. */
+int c2d_rects_from_poses(c2d_ctx* ctx, const float* d_cx, const float* d_cy, const float* d_w,
+                         const float* d_h, const float* d_theta, size_t n,
+                         float* const d_out_planes[8], c2d_stream stream);
+
+/* c2d_sat_rect_pairs_verts: batched rectangle-rectangle SAT — the arithmetic
+ * of convex_collide (utils.cu:159-184) applied to n independent pairs: 8 axes
+ * (the edge vectors of both rectangles, utils.cu:170-171), all 4+4 vertices
+ * projected with an unfused dot product (utils.cu:172-175), separated iff
+ * max1 < min2 || max2 < min1 (strict, utils.cu:178), no early result change.
+ * The reference only calls convex_collide from inside its MC kernel
+ * (compute_collision_probability.cu:138); this entry point is that function
+ * over SoA arrays.
+ *   d_planes[0..7]  : rectangle 1, planes x0,y0,x1,y1,x2,y2,x3,y3, each f32[n]
+ *   d_planes[8..15] : rectangle 2, same order
+ *   d_out           : u8[n], 1 = collide, 0 = separated
+ *   d_count         : optional (may be NULL) device uint64 that is *incremented*
+ *                     by the number of colliding pairs (atomically; zero it first).
+ * Any alignment is accepted; planes and d_out aligned to 16 B / 4 B take the
+ * wide-load path. */
+int c2d_sat_rect_pairs_verts(c2d_ctx* ctx, const float* const d_planes[16], size_t n,
+                             uint8_t* d_out, unsigned long long* d_count, c2d_stream stream);
+
+/* c2d_sat_rect_pairs_pose: the same test on pose-format input: for each pair,
+ * both rectangles are built on the fly exactly as c2d_rects_from_poses would
+ * (utils.cu:119-142) and then tested (utils.cu:159-184).
+ *   d_pose_planes[0..4] : rectangle 1: cx, cy, w, h, theta   (f32[n] each)
+ *   d_pose_planes[5..9] : rectangle 2: cx, cy, w, h, theta */
+int c2d_sat_rect_pairs_pose(c2d_ctx* ctx, const float* const d_pose_planes[10], size_t n,
+                            uint8_t* d_out, unsigned long long* d_count, c2d_stream stream);
+
+/* c2d_sat_poly_pairs: SAT for arbitrary convex polygons with up to
+ * C2D_POLY_KMAX vertices.  Same projection / strict-< interval test as
+ * utils.cu:172-180, but the axis of edge e is its true normal (-e.y, e.x):
+ * the reference's edge-as-axis shortcut (utils.cu:170-171) is only valid for
+ * rectangles.
+ *   d_vx, d_vy : f32[2][C2D_POLY_KMAX][n]   (polygon, vertex, pair) — pair index fastest
+ *   d_k        : u8[2][n]                    vertex counts, 1..C2D_POLY_KMAX
+ *   d_out      : u8[n] */
+int c2d_sat_poly_pairs(c2d_ctx* ctx, const float* d_vx, const float* d_vy, const uint8_t* d_k,
+                       size_t n, uint8_t* d_out, unsigned long long* d_count, c2d_stream stream);
+
+/* ---- random stream -----------------------------------------------------------
+ * Replaces setup_kernel + curand_normal (utils.cu:111-117, :146-150).  The
+ * generator is counter based: Philox4x32-10 with key = seed, counter =
+ * (2*sample + j, scene_id), j in {0,1} — identical to rocRAND's
+ * rocrand_state_philox4x32_10 initialised with (seed, subsequence = scene_id,
+ * offset = 8*sample).  No state array, no set-up kernel, results independent
+ * of launch geometry and of how samples are sharded over GPUs.
+ *
+ * c2d_philox_normals (parity/debug): for samples sample_begin .. +n writes the
+ * five N(0,1) draws in the reference's order dx,dy,dtheta,dw,dh
+ * (utils.cu:146-150) to d_normals[n][5] and, if d_raw != NULL, the eight raw
+ * 32-bit words to d_raw[n][8]. */
+int c2d_philox_normals(c2d_ctx* ctx, uint64_t seed, uint64_t scene_id, uint64_t sample_begin,
+                       size_t n, float* d_normals, uint32_t* d_raw, c2d_stream stream);
+
+/* ---- Monte-Carlo collision probability ---------------------------------------
+ *
+ * c2d_mc_pair: one scene, sample-parallel.  Replaces the body of
+ * monte_carlo_sample_collision_dataset_uniform for a single data point
+ * (compute_collision_probability.cu:119-139): robot = create_rect(robot_w,
+ * robot_h) rotated by pose->theta and moved to pos (:132-133); obstacle =
+ * create_rect(pose->width, pose->height) (:128); each sample perturbs the
+ * obstacle with sample_rectangle (utils.cu:144-157) and tests it with
+ * convex_collide (utils.cu:159-184).  Samples sample_begin .. sample_begin +
+ * n_samples - 1 of stream (seed, scene_id) are evaluated; *d_hits (device
+ * uint64) is incremented by the number of colliding samples.  Disjoint sample
+ * ranges may run on different GPUs and be summed. */
+int c2d_mc_pair(c2d_ctx* ctx, float robot_w, float robot_h, const Position* pos, const Pose* pose,
+                const StdDev* std_dev, uint64_t seed, uint64_t scene_id, uint64_t sample_begin,
+                uint64_t n_samples, unsigned long long* d_hits, c2d_stream stream);
+
+/* c2d_mc_scenes: many scenes with the reference's adaptive stopping rule.
+ * Replaces the host loop + kernel + thrust compaction of
+ * compute_collision_probability.cu:276-332 (= generate_dataset.cu:420-479):
+ * every scene is sampled in batches (C2D_MC_* schedule above); after each
+ * batch the 95 % half-width calcSlack (utils.cu:186-196, with the int
+ * overflow D1 fixed) is compared with bin_accuracy[getBin(p)]
+ * (utils.cu:198-207, with the out-of-bounds read D2 fixed); a scene stops at
+ * the first check that passes, or when n_samples >= max_samples.
+ * Scene i uses random stream (seed, scene_id_base + i), so results do not
+ * depend on batching, completion order or the number of GPUs.
+ * This call synchronises `stream` (the schedule is driven from the host). */
+typedef struct c2d_mc_scenes_args {
+    const Pose* d_poses;          /* device Pose[num_poses]          (utils.cu:91-94)  */
+    uint32_t num_poses;
+    const StdDev* d_std_devs;     /* device StdDev[num_std_devs] — standard deviations,
+                                     i.e. sqrt of variances.npy (ccp.cu:188-194)       */
+    uint32_t num_std_devs;
+    const PositionWithVarAndPoseIdx* d_scenes; /* device rows (x,y,var_idx,pose_idx)  */
+    size_t n_scenes;
+    float robot_w, robot_h;       /* ccp.cu:39-40 defaults 4.07 x 1.74                 */
+    const float* accuracy_bins;   /* host f32[n_accuracy_bins], e.g. {0,.01,.1,1}      */
+    const float* bin_accuracy;    /* host f32[n_accuracy_bins-1], e.g. {1e-4,1e-3,1e-2} */
+    uint32_t n_accuracy_bins;     /* <= 16                                             */
+    uint32_t max_samples;         /* ccp.cu:38 default 4000000                         */
+    uint64_t seed;
+    uint64_t scene_id_base;
+    uint32_t* d_hits;             /* device u32[n_scenes]  out: colliding samples      */
+    uint32_t* d_n_used;           /* device u32[n_scenes]  out: samples drawn          */
+    PoseCPVarAndPoseIdx* d_rows;  /* optional device rows (x,y,cp,var_idx,pose_idx) =
+                                     one output .npy row each (ccp.cu:337-344), cp =
+                                     hits / n_used (utils.cu:210-215)                  */
+    uint64_t* total_samples;      /* optional host out: sum of n_used                  */
+    uint32_t* iterations;         /* optional host out: schedule steps executed        */
+} c2d_mc_scenes_args;
+
+int c2d_mc_scenes(c2d_ctx* ctx, const c2d_mc_scenes_args* args, c2d_stream stream);
+
+/* c2d_sample_scenes: draws the scenes themselves, replacing the iteration==0
+ * branch of the generate_dataset kernel (generate_dataset.cu:207-219):
+ * pose_idx and var_idx uniform over the tables, robot placed on a ring around
+ * the obstacle (formula SURVEY.md §5.6).  Scene i uses stream
+ * (seed, scene_id_base + i) in a key domain disjoint from the MC samples. */
+int c2d_sample_scenes(c2d_ctx* ctx, const Pose* d_poses, uint32_t num_poses,
+                      const StdDev* d_std_devs, uint32_t num_std_devs, float robot_w,
+                      float robot_h, float spread, uint64_t seed, uint64_t scene_id_base,
+                      size_t n_scenes, PositionWithVarAndPoseIdx* d_scenes, c2d_stream stream);
+
+/* Host-side helpers with the reference's semantics, exported so that callers
+ * and tests see exactly what the device evaluates (utils.cu:186-207). */
+float c2d_calc_slack(uint32_t n_samples, uint32_t n_true);
+int c2d_get_bin(float p, const float* accuracy_bins, uint32_t n_accuracy_bins);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* C2D_H_ */

@@ -1,0 +1,61 @@
+/*
+ * utils.h — the rectangle / pose struct API of the collision engine.
+ *
+ * These PODs are the boundary types of the hot path.  Names and field order
+ * follow the reference's struct block (reference utils.cu:74-106; the
+ * reference's own utils.h is dead code) so that the reference's
+ * .npy rows and host drivers map onto them without repacking:
+ *
+ *   Position                  {x,y}                       utils.cu:74-77
+ *   PositionWithVarAndPoseIdx {x,y,var_idx,pose_idx}      utils.cu:79-84   (= one row of data_in/<k>.npy)
+ *   Variance / StdDev         {x,y,theta,width,height}    utils.cu:86-89,106
+ *   Pose                      {width,height,theta}        utils.cu:91-94
+ *   PoseCPVarAndPoseIdx       {x,y,cp,var_idx,pose_idx}   utils.cu:96-99   (= one row of data_out/<k>.npy)
+ *
+ * All fields are IEEE-754 binary32; indices are stored *as float* exactly as
+ * the reference does (utils.cu:82-83).  Plain C, usable from C, C++, HIP and
+ * (through ctypes) Python.
+ */
+#ifndef C2D_UTILS_H_
+#define C2D_UTILS_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct Position {
+    float x, y;
+} Position;
+
+typedef struct PositionWithVarAndPoseIdx {
+    float x, y;
+    float var_idx;
+    float pose_idx;
+} PositionWithVarAndPoseIdx;
+
+typedef struct Variance {
+    float x, y, theta, width, height;
+} Variance;
+
+typedef Variance StdDev;
+
+typedef struct Pose {
+    float width, height, theta;
+} Pose;
+
+typedef struct PoseCPVarAndPoseIdx {
+    float x, y, cp, var_idx, pose_idx;
+} PoseCPVarAndPoseIdx;
+
+/* A rectangle is a flat float[8]: x0,y0,x1,y1,x2,y2,x3,y3, counter-clockwise,
+ * starting at (-w/2,-h/2) (reference utils.cu:119-130). */
+#define C2D_RECT_FLOATS 8
+
+/* Arbitrary convex polygons carry at most this many vertices (BASELINE config 5). */
+#define C2D_POLY_KMAX 16
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* C2D_UTILS_H_ */

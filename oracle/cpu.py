@@ -1,0 +1,257 @@
+"""ctypes binding of oracle/libc2d_oracle.so (the C restatement).
+
+TEST INFRASTRUCTURE ONLY — see oracle/__init__.py.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libc2d_oracle.so")
+KMAX = 16
+
+
+class Position(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float)]
+
+
+class Pose(C.Structure):
+    _fields_ = [("width", C.c_float), ("height", C.c_float), ("theta", C.c_float)]
+
+
+class StdDev(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("theta", C.c_float),
+                ("width", C.c_float), ("height", C.c_float)]
+
+
+POSE_DT = np.dtype([("width", "<f4"), ("height", "<f4"), ("theta", "<f4")])
+STD_DT = np.dtype([("x", "<f4"), ("y", "<f4"), ("theta", "<f4"), ("width", "<f4"), ("height", "<f4")])
+SCENE_DT = np.dtype([("x", "<f4"), ("y", "<f4"), ("var_idx", "<f4"), ("pose_idx", "<f4")])
+ROW_DT = np.dtype([("x", "<f4"), ("y", "<f4"), ("cp", "<f4"), ("var_idx", "<f4"), ("pose_idx", "<f4")])
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with its Makefile if the .so is missing or stale."""
+    src = os.path.join(_HERE, "c2d_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-B", "libc2d_oracle.so"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        fp = C.POINTER(C.c_float)
+        L.c2d_oracle_num_threads.restype = C.c_int
+        L.c2d_oracle_logf.restype = C.c_float
+        L.c2d_oracle_logf.argtypes = [C.c_float]
+        L.c2d_oracle_sincosf.argtypes = [C.c_float, fp, fp]
+        L.c2d_oracle_sincos_u32.argtypes = [C.c_uint32, fp, fp]
+        L.c2d_oracle_convex_collide.restype = C.c_int
+        L.c2d_oracle_convex_collide.argtypes = [fp, fp]
+        L.c2d_oracle_calc_slack.restype = C.c_float
+        L.c2d_oracle_calc_slack.argtypes = [C.c_uint32, C.c_uint32]
+        L.c2d_oracle_get_bin.restype = C.c_int
+        L.c2d_oracle_get_bin.argtypes = [C.c_float, fp, C.c_uint32]
+        L.c2d_oracle_sat_rect_pairs_verts.restype = C.c_ulonglong
+        L.c2d_oracle_sat_rect_pairs_pose.restype = C.c_ulonglong
+        L.c2d_oracle_sat_poly_pairs.restype = C.c_ulonglong
+        L.c2d_oracle_mc_pair.restype = C.c_ulonglong
+        L.c2d_oracle_mc_pair.argtypes = [C.c_float, C.c_float, C.POINTER(Position), C.POINTER(Pose),
+                                         C.POINTER(StdDev), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
+        L.c2d_oracle_mc_scenes.restype = C.c_ulonglong
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a, ct=C.c_float):
+    return a.ctypes.data_as(C.POINTER(ct))
+
+
+def num_threads() -> int:
+    return lib().c2d_oracle_num_threads()
+
+
+def logf(u):
+    u = _f32(np.atleast_1d(u))
+    return np.array([lib().c2d_oracle_logf(float(v)) for v in u], dtype=np.float32)
+
+
+def sincosf(x):
+    x = _f32(np.atleast_1d(x))
+    s = np.empty_like(x)
+    c = np.empty_like(x)
+    L = lib()
+    sv, cv = C.c_float(), C.c_float()
+    for i, v in enumerate(x):
+        L.c2d_oracle_sincosf(float(v), C.byref(sv), C.byref(cv))
+        s[i], c[i] = sv.value, cv.value
+    return s, c
+
+
+def sincos_u32(y):
+    y = np.atleast_1d(np.asarray(y, dtype=np.uint32))
+    s = np.empty(y.shape, np.float32)
+    c = np.empty(y.shape, np.float32)
+    L = lib()
+    sv, cv = C.c_float(), C.c_float()
+    for i, v in enumerate(y):
+        L.c2d_oracle_sincos_u32(int(v), C.byref(sv), C.byref(cv))
+        s[i], c[i] = sv.value, cv.value
+    return s, c
+
+
+def philox(ctr, key):
+    ctr = np.ascontiguousarray(ctr, dtype=np.uint32)
+    key = np.ascontiguousarray(key, dtype=np.uint32)
+    out = np.empty(4, np.uint32)
+    lib().c2d_oracle_philox4x32_10(_ptr(ctr, C.c_uint32), _ptr(key, C.c_uint32), _ptr(out, C.c_uint32))
+    return out
+
+
+def raw8(seed, scene_id, sample_begin, n):
+    out = np.empty((n, 8), np.uint32)
+    L = lib()
+    for i in range(n):
+        L.c2d_oracle_raw8(C.c_uint64(seed), C.c_uint64(scene_id), C.c_uint64(sample_begin + i),
+                          out[i].ctypes.data_as(C.POINTER(C.c_uint32)))
+    return out
+
+
+def normals5(seed, scene_id, sample_begin, n):
+    out = np.empty((n, 5), np.float32)
+    L = lib()
+    for i in range(n):
+        L.c2d_oracle_normals5(C.c_uint64(seed), C.c_uint64(scene_id), C.c_uint64(sample_begin + i),
+                              out[i].ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def create_rect(w, h):
+    r = np.empty(8, np.float32)
+    lib().c2d_oracle_create_rect(_ptr(r), C.c_float(w), C.c_float(h))
+    return r
+
+
+def rot_trans_rectangle(r, dx, dy, dt):
+    r = _f32(r).copy()
+    lib().c2d_oracle_rot_trans_rectangle(_ptr(r), C.c_float(dx), C.c_float(dy), C.c_float(dt))
+    return r
+
+
+def convex_collide(r1, r2) -> int:
+    r1, r2 = _f32(r1), _f32(r2)
+    return lib().c2d_oracle_convex_collide(_ptr(r1), _ptr(r2))
+
+
+def rects_from_poses(cx, cy, w, h, theta):
+    """-> float32 [8][n] planes"""
+    cx, cy, w, h, theta = map(_f32, (cx, cy, w, h, theta))
+    n = cx.shape[0]
+    out = np.empty((8, n), np.float32)
+    arr = (C.POINTER(C.c_float) * 8)(*[_ptr(out[k]) for k in range(8)])
+    lib().c2d_oracle_rects_from_poses(_ptr(cx), _ptr(cy), _ptr(w), _ptr(h), _ptr(theta), C.c_size_t(n), arr)
+    return out
+
+
+def sat_rect_pairs_verts(planes):
+    """planes: float32 [16][n] -> (uint8 [n], count)"""
+    planes = _f32(planes)
+    assert planes.shape[0] == 16
+    n = planes.shape[1]
+    out = np.empty(n, np.uint8)
+    arr = (C.POINTER(C.c_float) * 16)(*[_ptr(planes[k]) for k in range(16)])
+    cnt = lib().c2d_oracle_sat_rect_pairs_verts(arr, C.c_size_t(n), _ptr(out, C.c_uint8))
+    return out, int(cnt)
+
+
+def sat_rect_pairs_pose(pp):
+    """pp: float32 [10][n] (cx,cy,w,h,theta for rect 1 then rect 2)"""
+    pp = _f32(pp)
+    assert pp.shape[0] == 10
+    n = pp.shape[1]
+    out = np.empty(n, np.uint8)
+    arr = (C.POINTER(C.c_float) * 10)(*[_ptr(pp[k]) for k in range(10)])
+    cnt = lib().c2d_oracle_sat_rect_pairs_pose(arr, C.c_size_t(n), _ptr(out, C.c_uint8))
+    return out, int(cnt)
+
+
+def sat_poly_pairs(vx, vy, k):
+    """vx, vy: float32 [2][KMAX][n]; k: uint8 [2][n]"""
+    vx, vy = _f32(vx), _f32(vy)
+    k = np.ascontiguousarray(k, dtype=np.uint8)
+    n = vx.shape[-1]
+    assert vx.shape == (2, KMAX, n) and k.shape == (2, n)
+    out = np.empty(n, np.uint8)
+    cnt = lib().c2d_oracle_sat_poly_pairs(_ptr(vx), _ptr(vy), _ptr(k, C.c_uint8), C.c_size_t(n),
+                                          _ptr(out, C.c_uint8))
+    if cnt == 2**64 - 1:
+        raise ValueError("vertex count outside 1..KMAX")
+    return out, int(cnt)
+
+
+def calc_slack(n, k) -> float:
+    return lib().c2d_oracle_calc_slack(int(n), int(k))
+
+
+def get_bin(p, bins) -> int:
+    bins = _f32(bins)
+    return lib().c2d_oracle_get_bin(C.c_float(p), _ptr(bins), len(bins))
+
+
+def mc_pair(robot_w, robot_h, pos, pose, sd, seed, scene_id, sample_begin, n_samples) -> int:
+    return int(lib().c2d_oracle_mc_pair(robot_w, robot_h, C.byref(Position(*pos)), C.byref(Pose(*pose)),
+                                        C.byref(StdDev(*sd)), seed, scene_id, sample_begin, n_samples))
+
+
+def mc_sampled_rect(pose, sd, seed, scene_id, sample):
+    out = np.empty(8, np.float32)
+    lib().c2d_oracle_mc_sampled_rect(C.byref(Pose(*pose)), C.byref(StdDev(*sd)), C.c_uint64(seed),
+                                     C.c_uint64(scene_id), C.c_uint64(sample), _ptr(out))
+    return out
+
+
+def mc_scenes(poses, std_devs, scenes, robot_w, robot_h, bins, acc, max_samples, seed, scene_id_base=0):
+    """poses: POSE_DT[np]; std_devs: STD_DT[nv]; scenes: SCENE_DT[n].
+    -> hits u32[n], n_used u32[n], rows ROW_DT[n], total samples"""
+    poses = np.ascontiguousarray(poses, dtype=POSE_DT)
+    std_devs = np.ascontiguousarray(std_devs, dtype=STD_DT)
+    scenes = np.ascontiguousarray(scenes, dtype=SCENE_DT)
+    bins, acc = _f32(bins), _f32(acc)
+    assert len(acc) == len(bins) - 1
+    n = scenes.shape[0]
+    hits = np.empty(n, np.uint32)
+    used = np.empty(n, np.uint32)
+    rows = np.empty(n, ROW_DT)
+    total = lib().c2d_oracle_mc_scenes(
+        C.c_void_p(poses.ctypes.data), C.c_uint32(len(poses)), C.c_void_p(std_devs.ctypes.data),
+        C.c_uint32(len(std_devs)), C.c_void_p(scenes.ctypes.data), C.c_size_t(n), C.c_float(robot_w),
+        C.c_float(robot_h), _ptr(bins), _ptr(acc), C.c_uint32(len(bins)), C.c_uint32(max_samples),
+        C.c_uint64(seed), C.c_uint64(scene_id_base), _ptr(hits, C.c_uint32), _ptr(used, C.c_uint32),
+        C.c_void_p(rows.ctypes.data))
+    return hits, used, rows, int(total)
+
+
+def sample_scenes(poses, std_devs, robot_w, robot_h, spread, seed, scene_id_base, n):
+    poses = np.ascontiguousarray(poses, dtype=POSE_DT)
+    std_devs = np.ascontiguousarray(std_devs, dtype=STD_DT)
+    scenes = np.empty(n, SCENE_DT)
+    lib().c2d_oracle_sample_scenes(
+        C.c_void_p(poses.ctypes.data), C.c_uint32(len(poses)), C.c_void_p(std_devs.ctypes.data),
+        C.c_uint32(len(std_devs)), C.c_float(robot_w), C.c_float(robot_h), C.c_float(spread),
+        C.c_uint64(seed), C.c_uint64(scene_id_base), C.c_size_t(n), C.c_void_p(scenes.ctypes.data))
+    return scenes

@@ -1,0 +1,142 @@
+"""sat.py — numpy restatement of the reference's rectangle SAT test.
+
+TEST INFRASTRUCTURE ONLY (the parity checker; never imported by the product
+path).  The reference README (README.md:3) names a ``SAT.py`` that is not in
+the reference snapshot; this file plays that role: an
+independent float32 restatement of ``create_rect`` (utils.cu:119-130) and
+``convex_collide`` (utils.cu:159-184), written against the reference source,
+not against oracle/c2d_oracle.c, so that the two oracles check each other
+bit for bit.
+
+PARITY UNPINNED: the reference holds no golden vectors for this path; see the
+header of oracle/c2d_oracle.c.
+
+All arithmetic is numpy float32: every ``*``, ``+``, ``-`` rounds to binary32
+and nothing is fused, which is the canonical arithmetic of DESIGN.md.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F32 = np.float32
+KMAX = 16
+
+
+def create_rect(w, h):
+    """utils.cu:119-130 — (n,) widths/heights -> (n, 8) flat x0,y0,..,x3,y3."""
+    w = np.asarray(w, dtype=F32)
+    h = np.asarray(h, dtype=F32)
+    two = F32(2)
+    r = np.empty(w.shape + (8,), dtype=F32)
+    r[..., 0] = -w / two
+    r[..., 1] = -h / two
+    r[..., 2] = w / two
+    r[..., 3] = -h / two
+    r[..., 4] = w / two
+    r[..., 5] = h / two
+    r[..., 6] = -w / two
+    r[..., 7] = h / two
+    return r
+
+
+def rot_trans_given_cs(r, dx, dy, c, s):
+    """utils.cu:136-141 with cos/sin supplied by the caller (the canonical
+    sin/cos lives in the C oracle; numpy has no float32 fma)."""
+    r = np.array(r, dtype=F32, copy=True)
+    dx = np.asarray(dx, dtype=F32)
+    dy = np.asarray(dy, dtype=F32)
+    c = np.asarray(c, dtype=F32)
+    s = np.asarray(s, dtype=F32)
+    for i in range(4):
+        x = r[..., 2 * i].copy()
+        y = r[..., 2 * i + 1].copy()
+        r[..., 2 * i] = (c * x - s * y) + dx
+        r[..., 2 * i + 1] = (s * x + c * y) + dy
+    return r
+
+
+def convex_collide(r1, r2):
+    """utils.cu:159-184 for (n, 8) float32 arrays -> (n,) uint8.
+
+    Axis = the edge vector itself (utils.cu:170-171), all eight axes always
+    evaluated, separation test strict ``<`` (utils.cu:178)."""
+    r1 = np.asarray(r1, dtype=F32)
+    r2 = np.asarray(r2, dtype=F32)
+    assert r1.shape == r2.shape and r1.shape[-1] == 8
+    collide = np.ones(r1.shape[:-1], dtype=bool)
+    for r in (r1, r2):
+        for i in range(4):
+            n0 = r[..., (i + 1) * 2 % 8] - r[..., i * 2]
+            n1 = r[..., ((i + 1) * 2 + 1) % 8] - r[..., i * 2 + 1]
+            p1 = np.stack([n0 * r1[..., k * 2] + n1 * r1[..., k * 2 + 1] for k in range(4)], axis=-1)
+            p2 = np.stack([n0 * r2[..., k * 2] + n1 * r2[..., k * 2 + 1] for k in range(4)], axis=-1)
+            max1, min1 = p1.max(axis=-1), p1.min(axis=-1)
+            max2, min2 = p2.max(axis=-1), p2.min(axis=-1)
+            sep = (max1 < min2) | (max2 < min1)
+            collide &= ~sep
+    return collide.astype(np.uint8)
+
+
+def convex_collide_scalar(r1, r2):
+    """Pure-Python loop form of utils.cu:159-184 for one pair (small cases)."""
+    r1 = [F32(v) for v in r1]
+    r2 = [F32(v) for v in r2]
+    collide = 1
+    for r in (r1, r2):
+        for i in range(4):
+            n0 = F32(r[(i + 1) * 2 % 8] - r[i * 2])
+            n1 = F32(r[((i + 1) * 2 + 1) % 8] - r[i * 2 + 1])
+            p1 = [F32(F32(n0 * r1[k * 2]) + F32(n1 * r1[k * 2 + 1])) for k in range(4)]
+            p2 = [F32(F32(n0 * r2[k * 2]) + F32(n1 * r2[k * 2 + 1])) for k in range(4)]
+            if max(p1) < min(p2) or max(p2) < min(p1):
+                collide = 0
+    return collide
+
+
+def poly_collide(ax, ay, ka, bx, by, kb):
+    """Convex polygon SAT with true normals for one pair;
+    ax/ay/bx/by are float32 sequences, ka/kb the vertex counts."""
+    A = [(F32(ax[i]), F32(ay[i])) for i in range(ka)]
+    B = [(F32(bx[i]), F32(by[i])) for i in range(kb)]
+    collide = 1
+    for P in (A, B):
+        kp = len(P)
+        for i in range(kp):
+            ex = F32(P[(i + 1) % kp][0] - P[i][0])
+            ey = F32(P[(i + 1) % kp][1] - P[i][1])
+            nx, ny = F32(-ey), ex
+            p1 = [F32(F32(nx * x) + F32(ny * y)) for x, y in A]
+            p2 = [F32(F32(nx * x) + F32(ny * y)) for x, y in B]
+            if max(p1) < min(p2) or max(p2) < min(p1):
+                collide = 0
+    return collide
+
+
+def poly_collide_batch(vx, vy, k):
+    """vx, vy: float32 [2][KMAX][n]; k: uint8 [2][n] -> uint8 [n] (vectorised
+    by masking padded vertices with +/-inf in the min/max)."""
+    vx = np.asarray(vx, dtype=F32)
+    vy = np.asarray(vy, dtype=F32)
+    k = np.asarray(k)
+    n = vx.shape[-1]
+    collide = np.ones(n, dtype=bool)
+    vidx = np.arange(KMAX)[:, None]
+    valid = [vidx < k[0][None, :], vidx < k[1][None, :]]
+    for p in range(2):
+        kp = k[p].astype(np.int64)
+        for i in range(KMAX):
+            has_edge = i < kp
+            if not has_edge.any():
+                break
+            i1 = np.where(i + 1 < kp, i + 1, 0)
+            cols = np.arange(n)
+            ex = vx[p][i1, cols] - vx[p][i]
+            ey = vy[p][i1, cols] - vy[p][i]
+            nx, ny = -ey, ex
+            with np.errstate(invalid="ignore", over="ignore"):
+                proj = [nx[None, :] * vx[q] + ny[None, :] * vy[q] for q in range(2)]
+            mn = [np.where(valid[q], proj[q], np.inf).min(axis=0) for q in range(2)]
+            mx = [np.where(valid[q], proj[q], -np.inf).max(axis=0) for q in range(2)]
+            sep = (mx[0] < mn[1]) | (mx[1] < mn[0])
+            collide &= ~(sep & has_edge)
+    return collide.astype(np.uint8)

@@ -1,0 +1,89 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every
+symbol include/c2d.h declares, its host-side helpers agree with the oracle, and
+the random stream is rocRAND's Philox4x32-10.  No compute entry point is called
+(no GPU here)."""
+import ctypes as C
+import os
+import re
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "c2d.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(c2d_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.load_library()
+    names = declared_symbols()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(lib, name), f"libc2d.so does not export {name}"
+    from c2d_amd import binding
+
+    assert sorted(binding.EXPORTED_SYMBOLS) == names, "python mirror and header disagree"
+
+
+def test_struct_layouts_match_reference_sizes(pkg):
+    # utils.cu:74-106: Position 8 B, PositionWithVarAndPoseIdx 16 B, Variance 20 B, Pose 12 B, PoseCPVarAndPoseIdx 20 B
+    assert pkg.SCENE_DT.itemsize == 16 and pkg.STD_DT.itemsize == 20
+    assert pkg.POSE_DT.itemsize == 12 and pkg.ROW_DT.itemsize == 20
+    assert pkg.SCENE_DT.names == ("x", "y", "var_idx", "pose_idx")
+    assert pkg.ROW_DT.names == ("x", "y", "cp", "var_idx", "pose_idx")
+    assert pkg.STD_DT.names == ("x", "y", "theta", "width", "height")
+    assert pkg.POSE_DT.names == ("width", "height", "theta")
+
+
+def test_version_and_status_strings(pkg):
+    lib = pkg.load_library()
+    assert lib.c2d_version() == 1
+    assert lib.c2d_status_string(0) == b"ok"
+    for st in (-1, -2, -3, -4, -5):
+        assert lib.c2d_status_string(st) not in (b"ok", b"unknown status")
+    assert lib.c2d_status_string(-99) == b"unknown status"
+
+
+def test_null_arguments_are_rejected_not_crashing(pkg):
+    lib = pkg.load_library()
+    assert lib.c2d_ctx_create(0, None) == -1
+    assert lib.c2d_device_count(None) == -1
+    assert lib.c2d_ctx_destroy(None) == 0
+    assert lib.c2d_malloc(None, None, 16) == -1
+    assert lib.c2d_sat_rect_pairs_verts(None, None, 10, None, None, None) == -1
+    assert lib.c2d_mc_scenes(None, None, None) == -1
+
+
+def test_host_stat_helpers_match_oracle(pkg, oracle):
+    lib = pkg.load_library()
+    rng = np.random.default_rng(0)
+    for n in (1000, 2000, 20000, 120000, 4020000):
+        for k in [0, 1, n // 3, n - 1, n] + list(rng.integers(0, n, 20)):
+            a = lib.c2d_calc_slack(int(n), int(k))
+            b = oracle.calc_slack(n, int(k))
+            assert np.float32(a).view(np.uint32) == np.float32(b).view(np.uint32)
+    bins = np.array([0, .01, .1, 1], np.float32)
+    for p in [0, .005, .01, .05, .1, .5, 1, 2] + list(rng.uniform(0, 1, 50)):
+        assert lib.c2d_get_bin(np.float32(p), bins.ctypes.data_as(C.POINTER(C.c_float)), 4) == oracle.get_bin(np.float32(p), bins)
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc + rocRAND headers")
+def test_stream_is_rocrand_philox(tmp_path, oracle):
+    """The c2d stream (seed, scene, sample) equals rocrand_state_philox4x32_10 with
+    rocrand_init(seed, subsequence=scene, offset=8*sample) — checked by running
+    rocRAND's own __host__ __device__ engine on the host."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = tmp_path / "rocrand_stream"
+    subprocess.run([hipcc, "-O1", "-x", "hip", "--cuda-host-only", "-I/opt/rocm/include",
+                    os.path.join(ROOT, "oracle", "tools", "rocrand_stream.cpp"), "-o", str(exe)], check=True)
+    for seed, scene, sample in [(0x0123456789ABCDEF, 0xFEDCBA9876543210, (1 << 33) - 4), (1234, 0, 0), (7, 1 << 32, 123456789)]:
+        out = subprocess.run([str(exe), str(seed), str(scene), str(sample), "8"], check=True, capture_output=True, text=True).stdout
+        ref = np.array([[int(v) for v in line.split()] for line in out.strip().splitlines()], np.uint32)
+        assert np.array_equal(oracle.raw8(seed, scene, sample, 8), ref)

@@ -1,0 +1,164 @@
+"""GPU parity tests of the random stream and the Monte-Carlo kernels through the
+C-ABI: raw Philox words, normals, hit counts and adaptive-stop results must be
+bit-identical to the CPU oracle; probabilities are checked against closed forms
+at 1e8 samples with the tolerance BASELINE.json states (1e-3)."""
+import math
+import os
+
+import numpy as np
+import pytest
+from scipy.stats import norm
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+W, H = 4.07, 1.74
+
+
+def gpu_hits(eng, pos, pose, sd, seed, scene, begin, n, robot=(W, H)):
+    d = eng.zeros(1, np.uint64)
+    eng.mc_pair(robot[0], robot[1], pos, pose, sd, seed, scene, begin, n, d)
+    h = int(d.get()[0])
+    d.free()
+    return h
+
+
+def test_philox_stream_golden_and_oracle(eng, oracle):
+    g = np.load(os.path.join(GOLD, "philox_stream.npz"))
+    seed, scene, begin = int(g["seed"]), int(g["scene"]), int(g["sample_begin"])
+    d_n, d_r = eng.empty((16, 5), np.float32), eng.empty((16, 8), np.uint32)
+    eng.philox_normals(seed, scene, begin, 16, d_n, d_r)
+    assert np.array_equal(d_r.get(), g["raw"])
+    assert np.array_equal(d_n.get().view(np.uint32), g["normals"].view(np.uint32))
+    # a longer run against the live oracle, bit for bit
+    n = 50000
+    d_n, d_r = eng.empty((n, 5), np.float32), eng.empty((n, 8), np.uint32)
+    eng.philox_normals(99, 12345, 10**12, n, d_n, d_r)
+    assert np.array_equal(d_r.get(), oracle.raw8(99, 12345, 10**12, n))
+    assert np.array_equal(d_n.get().view(np.uint32), oracle.normals5(99, 12345, 10**12, n).view(np.uint32))
+
+
+def test_mc_pair_golden_cases(eng):
+    g = np.load(os.path.join(GOLD, "mc_pair_cases.npz"))
+    rw, rh = (float(v) for v in g["robot"])
+    for prm, sid, want in zip(g["params"], g["scene_id"], g["hits"]):
+        got = gpu_hits(eng, tuple(prm[0:2]), tuple(prm[2:5]), tuple(prm[5:10]), int(g["seed"]), int(sid),
+                       int(g["sample_begin"]), int(g["n_samples"]), (rw, rh))
+        assert got == int(want)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 4097, 100000])
+def test_mc_pair_sizes_vs_oracle(eng, oracle, wl, n):
+    sc = wl.MC_PAIR_SCENE
+    got = gpu_hits(eng, sc["pos"], sc["pose"], sc["std_dev"], 1234, 5, 7, n)
+    assert got == oracle.mc_pair(W, H, sc["pos"], sc["pose"], sc["std_dev"], 1234, 5, 7, n)
+
+
+def test_mc_pair_shape_variance_and_zero_sigma(eng, oracle):
+    pos, pose = (2.9, -1.2), (1.5, 2.5, 1.1)
+    for sd in [(0.3, 0.2, 0.1, 0.4, 0.5), (0.0, 0.0, 0.0, 0.0, 0.0), (0.0, 0.0, 0.3, 0.0, 0.2), (0.2, 0.2, 0.0, 0.3, 0.0)]:
+        got = gpu_hits(eng, pos, pose, sd, 77, 1, 0, 50000)
+        assert got == oracle.mc_pair(W, H, pos, pose, sd, 77, 1, 0, 50000), sd
+
+
+def test_mc_pair_range_additivity_and_accumulation(eng, wl):
+    """Disjoint sample ranges sum to the whole (this is what sharding over GPUs relies on),
+    and d_hits accumulates across calls."""
+    sc = wl.MC_PAIR_SCENE
+    args = (sc["pos"], sc["pose"], sc["std_dev"], 1234, 0)
+    whole = gpu_hits(eng, *args, 0, 3_000_000)
+    d = eng.zeros(1, np.uint64)
+    for b, c in [(0, 1_000_001), (1_000_001, 999_999), (2_000_000, 1_000_000)]:
+        eng.mc_pair(W, H, *args, b, c, d)
+    assert int(d.get()[0]) == whole
+
+
+def test_mc_pair_1e8_closed_form(eng):
+    """BASELINE: MC probability within 1e-3 at 1e8 samples.  Closed forms of SURVEY.md §4.3."""
+    n = 100_000_000
+    px, sx, w, h = 3.4, 0.5, 2.0, 1.0
+    p = norm.cdf((px + (W + w) / 2) / sx) - norm.cdf((px - (W + w) / 2) / sx)
+    got = gpu_hits(eng, (px, 0.0), (w, h, 0.0), (sx, 0, 0, 0, 0), 7, 0, 0, n) / n
+    assert abs(got - p) < 1e-3, (got, p)
+    assert abs(got - p) < 5 * math.sqrt(p * (1 - p) / n) + 2e-5, (got, p)
+    py, sy = 1.6, 0.4
+    p = norm.cdf((py + (H + h) / 2) / sy) - norm.cdf((py - (H + h) / 2) / sy)
+    got = gpu_hits(eng, (0.0, py), (w, h, 0.0), (0, sy, 0, 0, 0), 8, 1, 0, n) / n
+    assert abs(got - p) < 1e-3 and abs(got - p) < 5 * math.sqrt(p * (1 - p) / n) + 2e-5, (got, p)
+
+
+def test_mc_pair_1e8_vs_oracle_sample(eng, oracle, wl):
+    """Config-3 scene at 1e8 samples: the oracle is too slow for 1e8, so compare the first
+    2e6 samples exactly and the 1e8 probability within 1e-3 of the oracle's 2e6 estimate + 4 sigma."""
+    sc = wl.MC_PAIR_SCENE
+    args = (sc["pos"], sc["pose"], sc["std_dev"], 1234, 0)
+    ref = oracle.mc_pair(W, H, *args, 0, 2_000_000)
+    assert gpu_hits(eng, *args, 0, 2_000_000) == ref
+    p8 = gpu_hits(eng, *args, 0, 100_000_000) / 1e8
+    p_ref = ref / 2e6
+    assert abs(p8 - p_ref) < 1e-3 + 4 * math.sqrt(p_ref * (1 - p_ref) / 2e6)
+
+
+def test_sample_scenes_matches_oracle(eng, oracle, wl, pkg):
+    poses, sds, _ = wl.random_tables(500, 300, seed=21, shape_variance=True)
+    n = 100_003
+    ref = oracle.sample_scenes(poses, sds, W, H, 4.0, 99, 1000, n)
+    d_p, d_s = eng.to_device(poses), eng.to_device(sds)
+    d_sc = eng.empty(n, pkg.SCENE_DT)
+    eng.sample_scenes(d_p, 500, d_s, 300, W, H, 4.0, 99, 1000, n, d_sc)
+    got = d_sc.get()
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def run_scenes(eng, pkg, poses, sds, scenes, max_samples, seed, base=0):
+    n = len(scenes)
+    d_p, d_s, d_sc = eng.to_device(poses), eng.to_device(sds), eng.to_device(scenes)
+    d_h, d_u, d_r = eng.zeros(n, np.uint32), eng.zeros(n, np.uint32), eng.empty(n, pkg.ROW_DT)
+    total, iters = eng.mc_scenes(d_p, len(poses), d_s, len(sds), d_sc, n, W, H, [0, .01, .1, 1], [1e-4, 1e-3, 1e-2],
+                                 max_samples, seed, base, d_h, d_u, d_r)
+    return d_h.get(), d_u.get(), d_r.get(), total, iters
+
+
+def test_mc_scenes_golden_64(eng, pkg):
+    g = np.load(os.path.join(GOLD, "mc_scenes_64.npz"))
+    hits, used, rows, total, iters = run_scenes(eng, pkg, g["poses"], g["std_devs"], g["scenes"], int(g["max_samples"]), int(g["seed"]))
+    assert np.array_equal(used, g["n_used"])
+    assert np.array_equal(hits, g["hits"])
+    assert np.array_equal(rows.view(np.uint32), g["rows"].view(np.uint32))
+    assert total == int(g["total"])
+    assert iters == 21  # 20 x 1000 then one 100000 batch reaches max_samples = 25000
+
+
+def test_mc_scenes_vs_oracle_early_stop(eng, oracle, wl, pkg):
+    """Scenes placed so that most stop early (p ~ 0.5 needs ~1e4 samples): exercises the
+    compaction of survivors and the per-scene stop decision."""
+    poses, sds, _ = wl.random_tables(40, 40, seed=31)
+    rng = np.random.default_rng(2)
+    n = 300
+    scenes = np.empty(n, pkg.SCENE_DT)
+    scenes["x"] = rng.uniform(-4, 4, n)
+    scenes["y"] = rng.uniform(-3, 3, n)
+    scenes["var_idx"] = rng.integers(0, 40, n)
+    scenes["pose_idx"] = rng.integers(0, 40, n)
+    ref_h, ref_u, ref_rows, ref_total = oracle.mc_scenes(poses, sds, scenes, W, H, [0, .01, .1, 1], [1e-4, 1e-3, 1e-2], 15000, 5, 700)
+    hits, used, rows, total, _ = run_scenes(eng, pkg, poses, sds, scenes, 15000, 5, base=700)
+    assert len(np.unique(ref_u)) > 3, "test no longer exercises several stop times"
+    assert np.array_equal(used, ref_u) and np.array_equal(hits, ref_h)
+    assert np.array_equal(rows.view(np.uint32), ref_rows.view(np.uint32))
+    assert total == ref_total
+
+
+def test_mc_scenes_sharding_is_invisible(eng, wl, pkg):
+    """Evaluating scenes [0,n) in one call equals evaluating two shards with the matching
+    scene_id_base — the multi-GPU partition of SURVEY.md §8e."""
+    poses, sds, _ = wl.random_tables(64, 64, seed=41)
+    d_p, d_s = eng.to_device(poses), eng.to_device(sds)
+    n = 5000
+    d_sc = eng.empty(n, pkg.SCENE_DT)
+    eng.sample_scenes(d_p, 64, d_s, 64, W, H, 4.0, 3, 0, n, d_sc)
+    scenes = d_sc.get()
+    h, u, r, tot, _ = run_scenes(eng, pkg, poses, sds, scenes, 3000, 8)
+    cut = 1777
+    h0, u0, r0, t0, _ = run_scenes(eng, pkg, poses, sds, scenes[:cut], 3000, 8, base=0)
+    h1, u1, r1, t1, _ = run_scenes(eng, pkg, poses, sds, scenes[cut:], 3000, 8, base=cut)
+    assert np.array_equal(h, np.concatenate([h0, h1])) and np.array_equal(u, np.concatenate([u0, u1]))
+    assert tot == t0 + t1

@@ -1,0 +1,229 @@
+"""CPU tests of the oracle itself: golden vectors, analytic known answers, and
+agreement of the two independent restatements (numpy and C).  The reference has
+no tests to mirror; these are the KATs that section derives."""
+import math
+import os
+
+import numpy as np
+import pytest
+from scipy.stats import norm
+
+from oracle import sat
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_golden_rect_1k_numpy_and_c_agree(oracle):
+    g = np.load(os.path.join(GOLD, "sat_rect_1k.npz"))
+    planes, expected = g["planes"], g["expected"]
+    got_c, cnt = oracle.sat_rect_pairs_verts(planes)
+    got_np = sat.convex_collide(planes[:8].T, planes[8:].T)
+    assert np.array_equal(got_c, expected)
+    assert np.array_equal(got_np, expected)
+    assert cnt == int(expected.sum())
+    # pure-Python scalar form on the KAT block and a few random ones
+    for i in list(range(int(g["n_kat"]))) + [100, 500, 999]:
+        assert sat.convex_collide_scalar(planes[:8, i], planes[8:, i]) == expected[i]
+
+
+def test_golden_rect_poses_rebuild_vertices(oracle):
+    g = np.load(os.path.join(GOLD, "sat_rect_1k.npz"))
+    k = int(g["n_kat"])
+    poses, planes = g["poses"][:, k:], g["planes"][:, k:]
+    r1 = oracle.rects_from_poses(*poses[:5])
+    r2 = oracle.rects_from_poses(*poses[5:])
+    assert np.array_equal(np.concatenate([r1, r2]).view(np.uint32), planes.view(np.uint32))
+    out, _ = oracle.sat_rect_pairs_pose(poses)
+    assert np.array_equal(out, g["expected"][k:])
+
+
+def test_sat_known_answers(oracle):
+    def rect(cx, cy, w, h):
+        return np.array([cx - w / 2, cy - h / 2, cx + w / 2, cy - h / 2, cx + w / 2, cy + h / 2, cx - w / 2, cy + h / 2], np.float32)
+
+    a = rect(0, 0, 2, 2)
+    assert oracle.convex_collide(a, a) == 1
+    assert oracle.convex_collide(a, rect(5, 0, 2, 2)) == 0
+    assert oracle.convex_collide(a, rect(2, 0, 2, 2)) == 1      # touching counts (strict <, utils.cu:178)
+    assert oracle.convex_collide(a, rect(2, 2, 2, 2)) == 1      # corner touching
+    assert oracle.convex_collide(a, rect(np.nextafter(np.float32(2), np.float32(3)), 0, 2, 2)) == 0
+    diamond = np.array([1.75, 0.75, 2.75, 1.75, 1.75, 2.75, 0.75, 1.75], np.float32)
+    assert oracle.convex_collide(a, diamond) == 0                # needs the rotated axes
+
+
+def test_sat_symmetry_and_cyclic_shift(oracle, wl):
+    poses = wl.random_obb_pose_planes(20000, seed=77, extent=4.0)
+    r1 = oracle.rects_from_poses(*poses[:5])
+    r2 = oracle.rects_from_poses(*poses[5:])
+    ab, _ = oracle.sat_rect_pairs_verts(np.concatenate([r1, r2]))
+    ba, _ = oracle.sat_rect_pairs_verts(np.concatenate([r2, r1]))
+    assert np.array_equal(ab, ba)
+    r1s = np.roll(r1, -2, axis=0)  # start the vertex list at vertex 1
+    sh, _ = oracle.sat_rect_pairs_verts(np.concatenate([r1s, r2]))
+    assert np.array_equal(ab, sh)
+    # exactly representable joint translation
+    t = np.float32(16.0)
+    tr, _ = oracle.sat_rect_pairs_verts(np.concatenate([r1 + t, r2 + t]))
+    assert (tr != ab).mean() < 1e-3  # translation changes rounding only on razor-edge pairs
+
+
+def test_create_rect_order(oracle):
+    r = oracle.create_rect(4.0, 2.0)
+    assert r.tolist() == [-2, -1, 2, -1, 2, 1, -2, 1]      # utils.cu:122-129, CCW from (-,-)
+    assert np.array_equal(sat.create_rect([4.0], [2.0])[0], r)
+
+
+def test_canonical_math_accuracy(oracle):
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-20, 20, 5000).astype(np.float32)
+    s, c = oracle.sincosf(x)
+    assert np.abs(s - np.sin(x.astype(np.float64))).max() < 2e-7
+    assert np.abs(c - np.cos(x.astype(np.float64))).max() < 2e-7
+    y = rng.integers(0, 2**32, 5000, dtype=np.uint64).astype(np.uint32)
+    y[:4] = [0, 0x20000000, 0x40000000, 0xFFFFFFFF]
+    s, c = oracle.sincos_u32(y)
+    a = y.astype(np.float64) * (2 * np.pi / 2**32)
+    assert np.abs(s - np.sin(a)).max() < 2e-7 and np.abs(c - np.cos(a)).max() < 2e-7
+    u = np.concatenate([rng.uniform(2.0**-33, 1, 5000), [2.0**-33, 1.0, 0.5, 2 / 3]]).astype(np.float32)
+    lg = oracle.logf(u)
+    ref = np.log(u.astype(np.float64))
+    assert np.abs(lg - ref).max() < 3e-6 and lg[-3] == 0.0
+    assert np.all(lg <= 0)
+
+
+def test_philox_known_answer(oracle):
+    # Random123 kat_vectors: philox4x32-10, counter = key = 0 / all ones / pi digits
+    assert oracle.philox([0, 0, 0, 0], [0, 0]).tolist() == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert oracle.philox([0xffffffff] * 4, [0xffffffff] * 2).tolist() == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert oracle.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]).tolist() == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_philox_stream_golden(oracle):
+    g = np.load(os.path.join(GOLD, "philox_stream.npz"))
+    raw = oracle.raw8(int(g["seed"]), int(g["scene"]), int(g["sample_begin"]), 16)
+    nrm = oracle.normals5(int(g["seed"]), int(g["scene"]), int(g["sample_begin"]), 16)
+    assert np.array_equal(raw, g["raw"])
+    assert np.array_equal(nrm.view(np.uint32), g["normals"].view(np.uint32))
+
+
+def test_normals_are_standard_normal(oracle):
+    n = oracle.normals5(42, 3, 0, 100000)
+    assert np.abs(n.mean(0)).max() < 0.02 and np.abs(n.std(0) - 1).max() < 0.02
+    assert np.abs(np.corrcoef(n.T) - np.eye(5)).max() < 0.02
+
+
+def test_calc_slack_and_get_bin(oracle):
+    # SURVEY.md §4.4
+    for n in (1000, 20000, 4020000):
+        assert oracle.calc_slack(n, 0) == pytest.approx(math.log(40.0) / n, rel=1e-6)
+        assert oracle.calc_slack(n, n) == pytest.approx(math.log(40.0) / n, rel=1e-6)
+    n, k = 20000, 5000
+    p = k / n
+    assert oracle.calc_slack(n, k) == pytest.approx(1.96 * math.sqrt(p * (1 - p) / n), rel=1e-5)
+    # D1: the reference's int*int overflows beyond 46 340 hits; the fix stays finite and correct
+    n, k = 4020000, 3000000
+    p = k / n
+    assert oracle.calc_slack(n, k) == pytest.approx(1.96 * math.sqrt(p * (1 - p) / n), rel=1e-3)
+    bins = [0.0, 0.01, 0.1, 1.0]
+    assert oracle.get_bin(0.0, bins) == 0
+    assert oracle.get_bin(0.005, bins) == 0
+    assert oracle.get_bin(np.float32(0.01), bins) == 1     # boundary goes to the higher bin (last match wins)
+    assert oracle.get_bin(0.05, bins) == 1
+    assert oracle.get_bin(np.float32(0.1), bins) == 2
+    assert oracle.get_bin(1.0, bins) == 2                  # D2: no read past the end
+    assert oracle.get_bin(2.0, bins) == 0                  # outside every bin -> 0, as the reference
+
+
+def test_mc_closed_form_x_only(oracle):
+    """robot theta=0 at (px, 0), only sigma_x > 0:
+    p = Phi((px+a)/sx) - Phi((px-a)/sx), a = (W_robot + w)/2."""
+    W, H, w, h, px, sx = 4.07, 1.74, 2.0, 1.0, 3.4, 0.5
+    n = 400000
+    hits = oracle.mc_pair(W, H, (px, 0.0), (w, h, 0.0), (sx, 0, 0, 0, 0), 7, 0, 0, n)
+    a = (W + w) / 2
+    p = norm.cdf((px + a) / sx) - norm.cdf((px - a) / sx)
+    assert abs(hits / n - p) < 4 * math.sqrt(p * (1 - p) / n) + 1e-4
+
+
+def test_mc_closed_form_y_only(oracle):
+    W, H, w, h, py, sy = 4.07, 1.74, 2.0, 1.0, 1.6, 0.4
+    n = 400000
+    hits = oracle.mc_pair(W, H, (0.0, py), (w, h, 0.0), (0, sy, 0, 0, 0), 8, 1, 0, n)
+    a = (H + h) / 2
+    p = norm.cdf((py + a) / sy) - norm.cdf((py - a) / sy)
+    assert abs(hits / n - p) < 4 * math.sqrt(p * (1 - p) / n) + 1e-4
+
+
+def test_mc_closed_form_width_only(oracle):
+    """Only sigma_w > 0 (shape variance): obstacle half width becomes w/2 + N(0, sw)/2;
+    collision iff |px| <= W/2 + w/2 + dw/2 (robot left of / right of the box)."""
+    W, H, w, h, px, sw = 4.07, 1.74, 2.0, 1.0, 3.3, 0.5
+    n = 400000
+    hits = oracle.mc_pair(W, H, (px, 0.0), (w, h, 0.0), (0, 0, 0, sw, 0), 9, 2, 0, n)
+    # hw + dw/2 >= px - W/2  <=>  dw >= 2*(px - W/2 - w/2); for negative half width the
+    # box is mirrored and still collides when |hw'| reaches the robot — negligible here
+    t = 2 * (px - W / 2 - w / 2) / sw
+    p = 1 - norm.cdf(t)
+    assert abs(hits / n - p) < 4 * math.sqrt(p * (1 - p) / n) + 1e-4
+
+
+def test_mc_pair_golden_and_range_additivity(oracle):
+    g = np.load(os.path.join(GOLD, "mc_pair_cases.npz"))
+    W, H = (float(v) for v in g["robot"])
+    prm = g["params"][0]
+    args = (W, H, tuple(prm[0:2]), tuple(prm[2:5]), tuple(prm[5:10]), int(g["seed"]), int(g["scene_id"][0]))
+    b = int(g["sample_begin"])
+    whole = oracle.mc_pair(*args, b, 20000)
+    parts = oracle.mc_pair(*args, b, 7001) + oracle.mc_pair(*args, b + 7001, 12999)
+    assert whole == parts
+
+
+def test_mc_scenes_golden_subset(oracle):
+    g = np.load(os.path.join(GOLD, "mc_scenes_64.npz"))
+    idx = np.where(g["n_used"] <= 9000)[0][:6]
+    scenes = g["scenes"][idx]
+    W, H = 4.07, 1.74
+    # scene ids are positional: evaluate each selected scene with its own id
+    for j, i in enumerate(idx):
+        hits, used, rows, _ = oracle.mc_scenes(g["poses"], g["std_devs"], scenes[j:j + 1], W, H, [0, .01, .1, 1],
+                                               [1e-4, 1e-3, 1e-2], int(g["max_samples"]), int(g["seed"]), int(i))
+        assert hits[0] == g["hits"][i] and used[0] == g["n_used"][i]
+        assert rows["cp"][0] == g["rows"]["cp"][i]
+
+
+def test_poly_golden_and_rect_consistency(oracle):
+    g = np.load(os.path.join(GOLD, "poly_k16_1k.npz"))
+    out, _ = oracle.sat_poly_pairs(g["vx"], g["vy"], g["k"])
+    assert np.array_equal(out, g["expected"])
+    assert np.array_equal(sat.poly_collide_batch(g["vx"], g["vy"], g["k"]), g["expected"])
+    # a rectangle pair fed through the polygon path (true normals) gives the same
+    # answer as the rectangle path (edge vectors) away from razor-edge cases
+    r = np.load(os.path.join(GOLD, "sat_rect_1k.npz"))
+    planes, n = r["planes"], 1000
+    vx = np.zeros((2, 16, n), np.float32)
+    vy = np.zeros((2, 16, n), np.float32)
+    for p in range(2):
+        for v in range(4):
+            vx[p, v] = planes[8 * p + 2 * v]
+            vy[p, v] = planes[8 * p + 2 * v + 1]
+    k = np.full((2, n), 4, np.uint8)
+    out, _ = oracle.sat_poly_pairs(vx, vy, k)
+    assert (out != r["expected"]).sum() <= 2
+
+
+def test_poly_rejects_bad_vertex_count(oracle):
+    vx = np.zeros((2, 16, 4), np.float32)
+    k = np.array([[3, 3, 0, 3], [3, 3, 3, 3]], np.uint8)
+    with pytest.raises(ValueError):
+        oracle.sat_poly_pairs(vx, vx, k)
+
+
+def test_sample_scenes_distribution(oracle, wl):
+    poses, sds, _ = wl.random_tables(64, 64, seed=3)
+    s = oracle.sample_scenes(poses, sds, 4.07, 1.74, 4.0, 5, 0, 4000)
+    assert s["pose_idx"].min() >= 0 and s["pose_idx"].max() < 64
+    assert s["var_idx"].min() >= 0 and s["var_idx"].max() < 64
+    assert len(np.unique(s["pose_idx"])) > 50
+    r = np.hypot(s["x"], s["y"])
+    assert 2.0 < np.median(r) < 12.0
