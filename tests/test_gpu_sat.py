@@ -113,11 +113,9 @@ def test_razor_edge_pairs(eng, oracle):
     cx = rng.uniform(-50, 50, n).astype(np.float32)
     cy = rng.uniform(-50, 50, n).astype(np.float32)
     # second rectangle shares the orientation and touches along the first one's +x edge
-    gap = ((w1 + w2) / 2).astype(np.float32)
-    ulps = rng.integers(-2, 3, n)
-    for _ in range(2):
-        gap = np.where(ulps > 0, np.nextafter(gap, np.float32(np.inf)), np.where(ulps < 0, np.nextafter(gap, np.float32(-np.inf)), gap))
-        ulps = ulps - np.sign(ulps)
+    # separation = touching distance +- k coordinate-ulps (ulp(64) = 2^-17 covers |c| < 64)
+    kk = (rng.integers(-8, 9, n) * 0.25).astype(np.float32)
+    gap = ((w1 + w2) / 2 + kk * np.float32(2.0**-17)).astype(np.float32)
     cx2 = (cx + gap * np.cos(th)).astype(np.float32)
     cy2 = (cy + gap * np.sin(th)).astype(np.float32)
     planes = np.concatenate([oracle.rects_from_poses(cx, cy, w1, h1, th), oracle.rects_from_poses(cx2, cy2, w2, h2, th)])
