@@ -14,7 +14,9 @@
  *     pointers on the context's device, everything else is host memory;
  *   - work is enqueued on the caller's stream (a hipStream_t passed as void*,
  *     NULL = the default stream) and is asynchronous unless stated otherwise;
- *   - a c2d_ctx is bound to one device; use one ctx per device / per host thread.
+ *   - a c2d_ctx is bound to one device and owns a small device workspace (partial
+ *     counts, adaptive-loop lists): use one ctx per device and per host thread, and
+ *     do not run two calls of the same ctx concurrently on different streams.
  *
  * Arithmetic contract (DESIGN.md §"Canonical arithmetic"): IEEE binary32,
  * round-to-nearest-even, no multiply-add contraction except where the spec
