@@ -11,7 +11,7 @@ SRCS := $(CSRC)/c2d_api.hip $(CSRC)/c2d_sat.hip $(CSRC)/c2d_mc.hip
 OBJS := $(SRCS:.hip=.o)
 HDRS := $(CSRC)/c2d_math.hpp $(CSRC)/c2d_internal.hpp include/c2d.h include/utils.h
 
-all: lib oracle
+all: lib oracle drivers
 
 lib: $(LIBDIR)/libc2d.so
 
@@ -25,11 +25,20 @@ $(LIBDIR)/libc2d.so: $(OBJS)
 oracle:
 	$(MAKE) -C oracle
 
+# CLI drivers: plain C++17 against the C-ABI only (no HIP headers needed)
+BINDIR := $(PKG)/bin
+HOST   := $(CSRC)/host
+CXX    ?= g++
+drivers: $(BINDIR)/generate_dataset $(BINDIR)/compute_collision_probability
+$(BINDIR)/%: $(HOST)/%.cpp $(HOST)/driver_common.hpp $(HOST)/npy.hpp $(HOST)/cli.hpp include/c2d.h include/utils.h $(LIBDIR)/libc2d.so
+	@mkdir -p $(BINDIR)
+	$(CXX) -O2 -std=c++17 -Wall -Wextra $< -o $@ -L$(LIBDIR) -lc2d -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath-link,/opt/rocm/lib
+
 clean:
-	rm -f $(OBJS) $(LIBDIR)/libc2d.so
+	rm -f $(OBJS) $(LIBDIR)/libc2d.so $(BINDIR)/generate_dataset $(BINDIR)/compute_collision_probability
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle clean
+.PHONY: all lib oracle drivers tools clean
 
 # developer tools (not shipped in libc2d.so)
 TOOLS := $(CSRC)/tools/sat_tune

@@ -1,0 +1,245 @@
+// generate_dataset — host driver with the reference's command-line surface and .npy outputs
+// (reference generate_dataset.cu:44-169 flags, :255-524 main), driving the HIP kernels through
+// the C-ABI of include/c2d.h.  Plain C++17: no HIP headers, no Boost, no libnpy.
+//
+// Differences from the reference, all deliberate:
+//   - directories are created before poses.npy / variances.npy are saved (D7);
+//   - the scene sampler and the Monte-Carlo loop use the counter-based stream of c2d.h, keyed by
+//     --seed (default: time based, as the reference's srand(time(0))) and the global scene index,
+//     so a run is reproducible and independent of how batches are sharded over GPUs;
+//   - --seed, --rank / --world_size / --device are additions; every reference flag is kept.
+#include "driver_common.hpp"
+
+struct Arguments {  // defaults: generate_dataset.cu:44-64
+    std::string data_dir = "./data/";
+    std::string pose_dir = "";
+    std::string variance_dir = "";
+    int num_batches = 100;
+    int batch_size = 100000;
+    int start_batch_count = 0;
+    int num_poses = 64 * 64 * 64 * 64;
+    int num_variances = 64 * 64 * 64 * 64;
+    int max_samples = 4000000;
+    std::vector<float> min_variance = {0.0, 0.0, 0.0, 0.0, 0.0};
+    std::vector<float> max_variance = {0.3, 0.3, 0.3, 0.3, 0.3};
+    std::vector<float> min_pose = {0.1, 0.1, 0.0};
+    std::vector<float> max_pose = {5, 5, static_cast<float>(2 * M_PI)};
+    std::vector<float> accuracy_bins = {0.0, 0.01, 0.1, 1.0};
+    std::vector<float> bin_accuracy = {0.0001, 0.001, 0.01};
+    float robot_width = 4.07;
+    float robot_height = 1.74;
+    float spread = 4;
+    bool shape_variance = false;
+    unsigned long long seed = 0;
+    bool seed_given = false;
+};
+
+static void need_size(const std::vector<float>& v, size_t n, const char* name)
+{
+    if (v.size() != n) throw std::runtime_error(std::string("--") + name + " needs exactly " + std::to_string(n) + " values");
+}
+
+int main(int argc, char* argv[])
+{
+    Arguments a;
+    cli::Parser p;
+    using K = cli::Option;
+    p.add("help", 0, K::SWITCH, "produce help message");
+    p.add("data_dir", 0, K::VALUE, "where to store the data");
+    p.add("num_batches", 'n', K::VALUE, "number of batches");
+    p.add("batch_size", 'b', K::VALUE, "number of samples per batch");
+    p.add("start_batch_count", 's', K::VALUE, "start value for batches");
+    p.add("num_poses", 0, K::VALUE, "number of poses");
+    p.add("num_variances", 0, K::VALUE, "number of variances");
+    p.add("shape_variance", 0, K::SWITCH, "whether or not to have shape variance");
+    p.add("max_samples", 0, K::VALUE, "maximum number of samples for z-test");
+    p.add("accuracy_bins", 0, K::MULTI, "accuracy bins e.g. 0 0.01 0.1 1");
+    p.add("bin_accuracy", 0, K::MULTI, "accuracy for each bin e.g. 0.0001 0.001 0.01");
+    p.add("min_variance", 0, K::MULTI, "min variance for each dimension (x y theta width height)");
+    p.add("max_variance", 0, K::MULTI, "max variance for each dimension");
+    p.add("min_pose", 0, K::MULTI, "min pose for each dimension (width height theta)");
+    p.add("max_pose", 0, K::MULTI, "max pose for each dimension");
+    p.add("robot_width", 'w', K::VALUE, "robot width");
+    p.add("robot_height", 'h', K::VALUE, "robot height");
+    p.add("spread", 0, K::VALUE, "spread of poses");
+    p.add("pose_dir", 0, K::VALUE, "poses .npy file to load instead of sampling");
+    p.add("variance_dir", 0, K::VALUE, "variances .npy file to load instead of sampling");
+    p.add("seed", 0, K::VALUE, "seed of the scene / Monte-Carlo streams (default: time based)");
+    p.add("rank", 0, K::VALUE, "this process' shard index (default: $RANK or 0)");
+    p.add("world_size", 0, K::VALUE, "number of shards = GPUs (default: $WORLD_SIZE or 1)");
+    p.add("device", 0, K::VALUE, "GPU index (default: $LOCAL_RANK or rank)");
+    Shard shard;
+    try {
+        p.parse(argc, argv);
+        if (p.has("help")) { p.print_help(std::cout); return 1; }
+        if (p.has("data_dir")) a.data_dir = p.str("data_dir");
+        if (p.has("num_batches")) a.num_batches = p.integer("num_batches");
+        if (p.has("batch_size")) a.batch_size = p.integer("batch_size");
+        if (p.has("start_batch_count")) a.start_batch_count = p.integer("start_batch_count");
+        if (p.has("num_poses")) a.num_poses = p.integer("num_poses");
+        if (p.has("num_variances")) a.num_variances = p.integer("num_variances");
+        if (p.has("max_samples")) a.max_samples = p.integer("max_samples");
+        if (p.has("accuracy_bins")) a.accuracy_bins = p.reals("accuracy_bins");
+        if (p.has("bin_accuracy")) a.bin_accuracy = p.reals("bin_accuracy");
+        if (p.has("min_variance")) { a.min_variance = p.reals("min_variance"); need_size(a.min_variance, 5, "min_variance"); }
+        if (p.has("max_variance")) { a.max_variance = p.reals("max_variance"); need_size(a.max_variance, 5, "max_variance"); }
+        if (p.has("min_pose")) { a.min_pose = p.reals("min_pose"); need_size(a.min_pose, 3, "min_pose"); }
+        if (p.has("max_pose")) { a.max_pose = p.reals("max_pose"); need_size(a.max_pose, 3, "max_pose"); }
+        if (p.has("robot_width")) a.robot_width = p.real("robot_width");
+        if (p.has("robot_height")) a.robot_height = p.real("robot_height");
+        if (p.has("spread")) a.spread = p.real("spread");
+        if (p.has("shape_variance")) a.shape_variance = true;
+        if (p.has("pose_dir")) a.pose_dir = p.str("pose_dir");
+        if (p.has("variance_dir")) a.variance_dir = p.str("variance_dir");
+        if (p.has("seed")) { a.seed = std::stoull(p.str("seed"), nullptr, 0); a.seed_given = true; }
+        shard = resolve_shard(p);
+        if (a.accuracy_bins.size() < 2 || a.bin_accuracy.size() + 1 != a.accuracy_bins.size())
+            throw std::runtime_error("--bin_accuracy needs one value fewer than --accuracy_bins");
+        if (a.batch_size <= 0 || a.num_batches < 0 || a.max_samples <= 0) throw std::runtime_error("sizes must be positive");
+    } catch (const std::exception& e) {
+        std::cerr << "error: " << e.what() << "\n";
+        p.print_help(std::cerr);
+        return EXIT_FAILURE;
+    }
+    const std::string& data_dir = a.data_dir;
+    std::cout << "data dir: " << data_dir << std::endl;
+    std::cout << "num batches: " << a.num_batches << std::endl;
+    std::cout << "num batch: " << a.batch_size << std::endl;
+    std::cout << "start batch count: " << a.start_batch_count << std::endl;
+
+    try {
+        mkdirs(data_dir);            // reference creates these only after saving (D7)
+        mkdirs(data_dir + "/meta");
+    } catch (const std::exception& e) {
+        std::cerr << "error: cannot create " << data_dir << ": " << e.what() << "\n";
+        return EXIT_FAILURE;
+    }
+
+    // Tables.  Same generator, distributions and draw order as the reference
+    // (generate_dataset.cu:279-332): std::default_random_engine, default seeded, all variances
+    // first, then all poses — so a libstdc++ build reproduces the reference's tables.
+    std::vector<float> variances, poses;  // flat [Nv][5], [Np][3]
+    std::default_random_engine generator;
+    try {
+        if (a.variance_dir.empty()) {
+            if (!a.shape_variance) {
+                a.min_variance[3] = a.max_variance[3] = 0.0f;
+                a.min_variance[4] = a.max_variance[4] = 0.0f;
+            }
+            std::vector<std::uniform_real_distribution<float>> u;
+            for (int i = 0; i < 5; i++) u.emplace_back(a.min_variance[i], a.max_variance[i]);
+            variances.resize(static_cast<size_t>(a.num_variances) * 5);
+            for (int i = 0; i < a.num_variances; i++)
+                for (int d = 0; d < 5; d++) variances[static_cast<size_t>(i) * 5 + d] = u[d](generator);
+            if (shard.rank == 0) npy::save_f32(data_dir + "/variances.npy", {static_cast<size_t>(a.num_variances), 5}, variances.data());
+        } else {
+            npy::Array v = npy::load_f32(a.variance_dir);
+            if (v.data.size() % 5) throw std::runtime_error("variances file is not [N,5]");
+            variances = std::move(v.data);
+            a.num_variances = static_cast<int>(variances.size() / 5);
+        }
+        if (a.pose_dir.empty()) {
+            std::vector<std::uniform_real_distribution<float>> u;
+            for (int i = 0; i < 3; i++) u.emplace_back(a.min_pose[i], a.max_pose[i]);
+            poses.resize(static_cast<size_t>(a.num_poses) * 3);
+            for (int i = 0; i < a.num_poses; i++)
+                for (int d = 0; d < 3; d++) poses[static_cast<size_t>(i) * 3 + d] = u[d](generator);
+            if (shard.rank == 0) npy::save_f32(data_dir + "/poses.npy", {static_cast<size_t>(a.num_poses), 3}, poses.data());
+        } else {
+            npy::Array v = npy::load_f32(a.pose_dir);
+            if (v.data.size() % 3) throw std::runtime_error("poses file is not [N,3]");
+            poses = std::move(v.data);
+            a.num_poses = static_cast<int>(poses.size() / 3);
+        }
+        if (shard.rank == 0) {
+            npy::save_f32(data_dir + "/meta/accuracy_bins.npy", {a.accuracy_bins.size()}, a.accuracy_bins.data());
+            npy::save_f32(data_dir + "/meta/bin_accuracy.npy", {a.bin_accuracy.size()}, a.bin_accuracy.data());
+        }
+    } catch (const std::exception& e) {
+        std::cerr << "error: " << e.what() << "\n";
+        return EXIT_FAILURE;
+    }
+    if (a.num_poses <= 0 || a.num_variances <= 0) { std::cerr << "error: empty pose / variance table\n"; return EXIT_FAILURE; }
+    std::vector<StdDev> std_devs = std_devs_from_variances(variances);
+    std::cout << "num poses: " << a.num_poses << std::endl;
+    std::cout << "num variances: " << a.num_variances << std::endl;
+
+    if (!a.seed_given) a.seed = static_cast<unsigned long long>(std::time(nullptr));  // reference: srand(time(0)), :406
+    std::cout << "seed: " << a.seed << std::endl;
+
+    c2d_ctx* ctx = nullptr;
+    C2D_CALL(ctx, c2d_ctx_create(shard.device, &ctx));
+    c2d_stream stream = nullptr;
+    C2D_CALL(ctx, c2d_stream_create(ctx, &stream));
+    const size_t B = static_cast<size_t>(a.batch_size);
+    void *d_poses = nullptr, *d_sd = nullptr, *d_scenes = nullptr, *d_hits = nullptr, *d_used = nullptr, *d_rows = nullptr;
+    C2D_CALL(ctx, c2d_malloc(ctx, &d_poses, poses.size() * sizeof(float)));
+    C2D_CALL(ctx, c2d_malloc(ctx, &d_sd, std_devs.size() * sizeof(StdDev)));
+    C2D_CALL(ctx, c2d_malloc(ctx, &d_scenes, B * sizeof(PositionWithVarAndPoseIdx)));
+    C2D_CALL(ctx, c2d_malloc(ctx, &d_hits, B * sizeof(uint32_t)));
+    C2D_CALL(ctx, c2d_malloc(ctx, &d_used, B * sizeof(uint32_t)));
+    C2D_CALL(ctx, c2d_malloc(ctx, &d_rows, B * sizeof(PoseCPVarAndPoseIdx)));
+    C2D_CALL(ctx, c2d_memcpy_h2d(ctx, d_poses, poses.data(), poses.size() * sizeof(float), stream));
+    C2D_CALL(ctx, c2d_memcpy_h2d(ctx, d_sd, std_devs.data(), std_devs.size() * sizeof(StdDev), stream));
+    C2D_CALL(ctx, c2d_stream_synchronize(ctx, stream));
+
+    std::vector<PoseCPVarAndPoseIdx> dataset(B);
+    std::vector<uint32_t> hits(B);
+    const auto begin = std::chrono::steady_clock::now();
+    std::cout << "Total number of configurations: " << static_cast<long long>(a.batch_size) * a.num_batches << std::endl;
+    std::cout << "Begin computation..." << std::endl;
+    int counter = 0;
+    RunStats stats;
+    std::printf("batches generated: %i/%i", counter, a.num_batches);
+    for (int batch_index = shard.rank; batch_index < a.num_batches; batch_index += shard.world) {
+        const uint64_t scene_base = (static_cast<uint64_t>(a.start_batch_count) + batch_index) * B;
+        // iteration == 0 branch of the reference kernel: draw the scenes (:207-219)
+        C2D_CALL(ctx, c2d_sample_scenes(ctx, static_cast<const Pose*>(d_poses), a.num_poses, static_cast<const StdDev*>(d_sd),
+                                        a.num_variances, a.robot_width, a.robot_height, a.spread, a.seed, scene_base, B,
+                                        static_cast<PositionWithVarAndPoseIdx*>(d_scenes), stream));
+        c2d_mc_scenes_args m{};
+        m.d_poses = static_cast<const Pose*>(d_poses); m.num_poses = a.num_poses;
+        m.d_std_devs = static_cast<const StdDev*>(d_sd); m.num_std_devs = a.num_variances;
+        m.d_scenes = static_cast<const PositionWithVarAndPoseIdx*>(d_scenes); m.n_scenes = B;
+        m.robot_w = a.robot_width; m.robot_h = a.robot_height;
+        m.accuracy_bins = a.accuracy_bins.data(); m.bin_accuracy = a.bin_accuracy.data();
+        m.n_accuracy_bins = static_cast<uint32_t>(a.accuracy_bins.size());
+        m.max_samples = static_cast<uint32_t>(a.max_samples);
+        m.seed = a.seed; m.scene_id_base = scene_base;
+        m.d_hits = static_cast<uint32_t*>(d_hits); m.d_n_used = static_cast<uint32_t*>(d_used);
+        m.d_rows = static_cast<PoseCPVarAndPoseIdx*>(d_rows);
+        uint64_t total = 0;
+        m.total_samples = &total;
+        C2D_CALL(ctx, c2d_mc_scenes(ctx, &m, stream));  // adaptive loop, :425-479
+        C2D_CALL(ctx, c2d_memcpy_d2h(ctx, dataset.data(), d_rows, B * sizeof(PoseCPVarAndPoseIdx), stream));
+        C2D_CALL(ctx, c2d_memcpy_d2h(ctx, hits.data(), d_hits, B * sizeof(uint32_t), stream));
+        C2D_CALL(ctx, c2d_stream_synchronize(ctx, stream));
+        stats.samples += total;
+        stats.scenes += B;
+        for (uint32_t h : hits) stats.hits += h;
+        std::shuffle(dataset.begin(), dataset.end(), std::default_random_engine(0));  // :496
+        try {
+            npy::save_f32(data_dir + "/" + std::to_string(a.start_batch_count + batch_index) + ".npy", {B, 5},
+                          reinterpret_cast<const float*>(dataset.data()));  // :499-500
+        } catch (const std::exception& e) {
+            std::cerr << "\nerror: " << e.what() << "\n";
+            return EXIT_FAILURE;
+        }
+        const auto now = std::chrono::steady_clock::now();
+        std::printf("\33[2K\r");
+        std::printf("batches generated: %i/%i, Time: %i [min]", ++counter, a.num_batches,
+                    static_cast<int>(std::chrono::duration_cast<std::chrono::minutes>(now - begin).count()));
+        std::fflush(stdout);
+    }
+    std::cout << std::endl;
+    const auto end = std::chrono::steady_clock::now();
+    stats.seconds = std::chrono::duration<double>(end - begin).count();
+    std::cout << "Finished computation" << std::endl;
+    std::cout << "Elapsed time: " << std::chrono::duration_cast<std::chrono::minutes>(end - begin).count() << " [min]" << std::endl;
+    print_json_summary("generate_dataset", shard, stats, counter);
+    for (void* ptr : {d_poses, d_sd, d_scenes, d_hits, d_used, d_rows}) c2d_free(ctx, ptr);
+    c2d_stream_destroy(ctx, stream);
+    c2d_ctx_destroy(ctx);
+    std::cout << "Done." << std::endl;
+    return 0;
+}

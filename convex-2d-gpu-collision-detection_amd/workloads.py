@@ -81,11 +81,3 @@ def random_tables(num_poses: int, num_variances: int, seed: int = 7, shape_varia
     poses[:, 1] = rng.uniform(0.1, 5.0, num_poses)
     poses[:, 2] = rng.uniform(0.0, 2.0 * np.pi, num_poses)
     return poses.view(POSE_DT).reshape(-1), sd.view(STD_DT).reshape(-1), var
-
-
-def shard_range(total: int, rank: int, world: int):
-    """Contiguous range partition [begin, end) of `total` units for `rank` of `world`
-    (SURVEY.md §8e): the first total % world ranks get one extra unit."""
-    base, rem = divmod(total, world)
-    begin = rank * base + min(rank, rem)
-    return begin, begin + base + (1 if rank < rem else 0)

@@ -1,0 +1,107 @@
+"""world_size-2 gloo tests of the multi-GPU path's host logic: range
+sharding + one all-reduce of the counters.  The per-rank compute here is the CPU oracle
+(test stand-in for the HIP kernels, which need a GPU); the property under test is that
+shards + reduce reproduce the single-process result exactly."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from __graft_entry__ import load_package
+
+    load_package()
+    import importlib
+
+    sh = importlib.import_module("c2d_amd.sharding")
+    wl = importlib.import_module("c2d_amd.workloads")
+    from oracle import cpu as oracle
+
+    # (1) MC single pair: sample index space split over ranks, one all-reduce of the hits
+    S = 200_001
+    b, e = sh.shard_range(S, rank, world)
+    sc = wl.MC_PAIR_SCENE
+    local = oracle.mc_pair(sc["robot_w"], sc["robot_h"], sc["pos"], sc["pose"], sc["std_dev"], 1234, 0, b, e - b)
+    hits, samples = sh.all_reduce_counters([local, e - b])
+
+    # (2) pair batch: contiguous range partition, count reduced
+    n = 30_001
+    poses = wl.random_obb_pose_planes(n, seed=3, extent=3.0)
+    pb, pe = sh.shard_range(n, rank, world)
+    planes = np.concatenate([oracle.rects_from_poses(*poses[:5, pb:pe]), oracle.rects_from_poses(*poses[5:, pb:pe])])
+    out, cnt = oracle.sat_rect_pairs_verts(planes)
+    (total_cnt,) = sh.all_reduce_counters([cnt])
+
+    # (3) scenes: scene ranges per rank with scene_id_base = range begin
+    tp, ts, _ = wl.random_tables(16, 16, seed=4)
+    scenes = oracle.sample_scenes(tp, ts, 4.07, 1.74, 4.0, 5, 0, 41)
+    sb, se = sh.shard_range(41, rank, world)
+    h, u, _, tot = oracle.mc_scenes(tp, ts, scenes[sb:se], 4.07, 1.74, [0, .01, .1, 1], [1e-4, 1e-3, 1e-2], 2000, 8, sb)
+    scene_hits, scene_samples = sh.all_reduce_counters([int(h.sum()), tot])
+    tmax = sh.max_over_ranks(1.0 + rank)
+    if rank == 0:
+        q.put((hits, samples, total_cnt, scene_hits, scene_samples, tmax))
+    dist.destroy_process_group()
+
+
+def test_shard_range_partitions_exactly(pkg):
+    import importlib
+
+    sh = importlib.import_module("c2d_amd.sharding")
+    for total in (0, 1, 7, 8, 10**7, 10**8 + 3):
+        for world in (1, 2, 3, 8):
+            r = [sh.shard_range(total, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == total
+            assert all(r[i][1] == r[i + 1][0] for i in range(world - 1))
+            sizes = [e - b for b, e in r]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        sh.shard_range(10, 2, 2)
+
+
+def test_two_rank_gloo_sharding_reproduces_single_process(oracle, wl):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    hits, samples, total_cnt, scene_hits, scene_samples, tmax = res
+    sc = wl.MC_PAIR_SCENE
+    assert samples == 200_001
+    assert hits == oracle.mc_pair(sc["robot_w"], sc["robot_h"], sc["pos"], sc["pose"], sc["std_dev"], 1234, 0, 0, 200_001)
+    poses = wl.random_obb_pose_planes(30_001, seed=3, extent=3.0)
+    planes = np.concatenate([oracle.rects_from_poses(*poses[:5]), oracle.rects_from_poses(*poses[5:])])
+    assert total_cnt == oracle.sat_rect_pairs_verts(planes)[1]
+    tp, ts, _ = wl.random_tables(16, 16, seed=4)
+    scenes = oracle.sample_scenes(tp, ts, 4.07, 1.74, 4.0, 5, 0, 41)
+    h, u, _, tot = oracle.mc_scenes(tp, ts, scenes, 4.07, 1.74, [0, .01, .1, 1], [1e-4, 1e-3, 1e-2], 2000, 8, 0)
+    assert scene_hits == int(h.sum()) and scene_samples == tot
+    assert tmax == 2.0
