@@ -35,6 +35,35 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_PAIR = 65            # 16 planes x 4 B read + 1 B written
 FP32_VALU_PEAK_TFLOPS = 157.3  # spec, FMA counted as 2
+VALU_INSTR_PER_SAMPLE = 449    # MC sample loop, sigma_h = 0
+KMAX = 16
+
+
+def torch_random_convex_polygons(torch, dev, n, seed, kmin=3, kmax=KMAX, extent=8.0):
+    """Device-side twin of workloads.random_convex_polygons (config 5 input)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    vx = torch.zeros((2, KMAX, n), dtype=torch.float32, device=dev)
+    vy = torch.zeros_like(vx)
+    k = torch.randint(kmin, kmax + 1, (2, n), generator=g, device=dev, dtype=torch.int32)
+    for p in range(2):
+        mask = torch.arange(KMAX, device=dev)[:, None] >= k[p][None, :]
+        ang = torch.rand((KMAX, n), generator=g, device=dev) * (2 * np.pi)
+        ang[mask] = float("inf")
+        ang, _ = torch.sort(ang, dim=0)
+        ang[mask] = 0
+        a = torch.rand(n, generator=g, device=dev) * 2.2 + 0.3
+        b = torch.rand(n, generator=g, device=dev) * 2.2 + 0.3
+        rot = torch.rand(n, generator=g, device=dev) * (2 * np.pi)
+        cx = (torch.rand(n, generator=g, device=dev) * 2 - 1) * extent
+        cy = (torch.rand(n, generator=g, device=dev) * 2 - 1) * extent
+        x, y = a[None] * torch.cos(ang), b[None] * torch.sin(ang)
+        c, s = torch.cos(rot)[None], torch.sin(rot)[None]
+        vx[p] = c * x - s * y + cx[None]
+        vy[p] = s * x + c * y + cy[None]
+        vx[p][mask] = 0
+        vy[p][mask] = 0
+    return vx, vy, k.to(torch.uint8)
 
 
 def main() -> None:
@@ -51,6 +80,10 @@ def main() -> None:
                          "up to 12 %% slower while the power manager ramps clocks (profiles/r01a trace)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mc", action="store_true")
+    ap.add_argument("--scenes", type=int, default=4_000_000,
+                    help="config 4 data points per GPU (1e6 scenes x 32 obstacle instances / 8 GPUs); 0 = skip the leg")
+    ap.add_argument("--scenes-max-samples", type=int, default=120_000)
+    ap.add_argument("--poly-pairs", type=int, default=10_000_000, help="config 5 polygon pairs per GPU; 0 = skip the leg")
     args = ap.parse_args()
 
     import torch
@@ -62,6 +95,7 @@ def main() -> None:
     import importlib
 
     wl = importlib.import_module("c2d_amd.workloads")
+    shd = importlib.import_module("c2d_amd.sharding")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -138,11 +172,7 @@ def main() -> None:
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = shd.max_over_ranks(t1 - t0, dev)
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # average launch duration on the kernel's stream
     pairs_total = n * world * args.steps
     value = pairs_total / elapsed
@@ -192,16 +222,85 @@ def main() -> None:
         torch.cuda.synchronize()
         barrier()
         m1 = time.perf_counter()
-        mel = m1 - m0
-        if world > 1:
-            tm = torch.tensor([mel], dtype=torch.float64, device=dev)
-            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-            mel = float(tm.item())
+        mel = shd.max_over_ranks(m1 - m0, dev)
         mc_kernel_ms = e0.elapsed_time(e1) / args.mc_reps
         p = float(hits.item()) / (S * world * args.mc_reps)
         mc = {"metric": "mc_samples_per_s", "value": S * world * args.mc_reps / mel, "samples_per_gpu": S, "reps": args.mc_reps,
               "kernel_ms": round(mc_kernel_ms, 4), "probability": p, "scene": "config3: robot 4.07x1.74 at (3,1) th=0.6, obstacle 2x1, sigma=(.3,.3,.2,0,0)",
               "bound": "valu", "note": "~0 HBM bytes per sample; VALU/transcendental bound (DESIGN.md)"}
+
+    if mc is not None:
+        # 449 VALU instructions per sample in the sample loop (counted in the gfx950 ISA)
+        lane_ops = mc["value"] / world * VALU_INSTR_PER_SAMPLE / 1e12
+        mc["roofline"] = {"bound": "valu", "achieved": round(lane_ops, 2), "peak": FP32_VALU_PEAK_TFLOPS / 2,
+                          "unit": "T VALU lane-instr/s per GPU (peak = 157.3 TFLOP/s / 2 flop per FMA)",
+                          "frac": round(lane_ops / (FP32_VALU_PEAK_TFLOPS / 2), 4), "valu_instr_per_sample": VALU_INSTR_PER_SAMPLE}
+
+    # ---- config 4: adaptive Monte-Carlo over many scenes -------------------------------------
+    scenes_leg = None
+    if args.scenes > 0:
+        ns = args.scenes
+        tp, ts, _ = wl.random_tables(65536, 65536, seed=7)
+        d_p, d_s = eng.to_device(tp), eng.to_device(ts)
+        d_sc = eng.empty(ns, pkg.SCENE_DT)
+        base = rank * ns  # scene ids (hence random streams) are global: rank r owns [r*ns, (r+1)*ns)
+        eng.sample_scenes(d_p, 65536, d_s, 65536, 4.07, 1.74, 4.0, 7, base, ns, d_sc, stream=sh)
+        d_h, d_u = eng.zeros(ns, np.uint32, stream=sh), eng.zeros(ns, np.uint32, stream=sh)
+        eng.synchronize(sh)
+        barrier()
+        s0 = time.perf_counter()
+        total, iters = eng.mc_scenes(d_p, 65536, d_s, 65536, d_sc, ns, 4.07, 1.74, wl.DEFAULT_BINS, wl.DEFAULT_BIN_ACCURACY,
+                                     args.scenes_max_samples, 11, base, d_h, d_u, None, stream=sh)
+        hsum = torch.zeros(2, dtype=torch.int64, device=dev)
+        hsum[0] = int(d_h.get().astype(np.int64).sum())
+        hsum[1] = total
+        if world > 1:
+            dist.all_reduce(hsum, op=dist.ReduceOp.SUM)  # hit and sample totals: the one collective
+        torch.cuda.synchronize()
+        barrier()
+        sel = shd.max_over_ranks(time.perf_counter() - s0, dev)
+        scenes_leg = {"metric": "mc_samples_per_s", "value": float(hsum[1].item()) / sel, "data_points_per_gpu": ns,
+                      "max_samples": args.scenes_max_samples, "schedule_steps": iters, "seconds": round(sel, 4),
+                      "data_points_per_s": ns * world / sel, "mean_samples_per_point": float(hsum[1].item()) / (ns * world),
+                      "pooled_hit_fraction": float(hsum[0].item()) / float(hsum[1].item()),
+                      "workload": "config4: scenes drawn by the generate_dataset formula from 65536-entry tables, adaptive stopping"}
+        for a_ in (d_p, d_s, d_sc, d_h, d_u):
+            a_.free()
+
+    # ---- config 5: convex polygons K <= 16 ---------------------------------------------------------
+    poly_leg = None
+    if args.poly_pairs > 0:
+        npoly = args.poly_pairs
+        vx, vy, kk = torch_random_convex_polygons(torch, dev, npoly, seed=0xC0FFEE + rank)
+        pout = torch.empty(npoly, dtype=torch.uint8, device=dev)
+        pcnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+
+        def poly_step():
+            eng.sat_poly_pairs(vx.data_ptr(), vy.data_ptr(), kk.data_ptr(), npoly, pout.data_ptr(), pcnt.data_ptr(), stream=sh)
+
+        for _ in range(3):
+            poly_step()
+        torch.cuda.synchronize()
+        pcnt.zero_()
+        barrier()
+        torch.cuda.synchronize()
+        p0 = time.perf_counter()
+        preps = 10
+        for _ in range(preps):
+            poly_step()
+        if world > 1:
+            with torch.cuda.stream(stream):
+                dist.all_reduce(pcnt, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        barrier()
+        pel = shd.max_over_ranks(time.perf_counter() - p0, dev)
+        exact_bytes = int(kk.to(torch.int64).sum().item()) * 8 + 3 * npoly
+        poly_leg = {"metric": "poly_pair_tests_per_s", "value": npoly * world * preps / pel, "pairs_per_gpu": npoly, "reps": preps,
+                    "ms_per_pass": pel / preps * 1e3, "collide_rate": float(pcnt.item()) / (npoly * world * preps),
+                    "padded_GBs_per_gpu": 259 * npoly * preps / pel / 1e9, "exact_GBs_per_gpu": exact_bytes * preps / pel / 1e9,
+                    "bound": "valu/lds", "workload": "config5: K ~ U{3..16} convex polygons, SoA [2][16][n], true normals"}
+        del vx, vy, kk, pout
 
     # ---- CPU baseline: oracle port on this host, rank 0, N = 1 only ------------------------------
     cpu_baseline = None
@@ -243,7 +342,7 @@ def main() -> None:
             "config": {"workload": "config2: 1e7 random OBB pairs per GPU, 16 SoA vertex planes -> u8 booleans, single SAT overlap kernel",
                        "pairs_per_gpu": n, "bytes_per_pair": BYTES_PER_PAIR, "collide_rate": round(collide_rate, 5),
                        "parallelism": f"pairs sharded over {world} GPU(s), one RCCL all-reduce of the hit count"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "mc": mc,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "mc": mc, "scenes": scenes_leg, "poly": poly_leg,
             "device": eng.info()["name"],
         }
         print(json.dumps(line), flush=True)

@@ -147,21 +147,32 @@ __global__ __launch_bounds__(kBlock) void rects_from_poses_kernel(const float* _
 // ---- convex polygons, K <= 16, true normals ----------------------------------------
 // Work split: 32 lanes per pair, lane a owns axis a (edge a of polygon A for
 // a < ka, edge a-ka of polygon B otherwise), so all ka+kb axes of a pair are
-// evaluated side by side and the "found a separating axis" decision is one
-// ballot.  Vertices are staged in LDS by the whole block with coalesced loads
-// (pair index fastest in memory), then every lane walks the pair's vertex list
-// with broadcast LDS reads.  A block handles kPolyPairs pairs per pass.
+// evaluated side by side and "found a separating axis" is one ballot (the
+// wave-level equivalent of an early-out: no axis is ever evaluated after the
+// decision is known, because they all run at once).  Vertices are staged in LDS
+// by the whole block with coalesced loads (pair index fastest in memory), then
+// every lane walks the pair's vertex list two vertices per ds_read_b128; all
+// lanes of a half-wave read the same address (LDS broadcast).  The vertex lists
+// are padded to an even length by repeating the last vertex, which cannot
+// change a min or a max.  A block handles kPolyPairs pairs per pass.
 constexpr int kPolyPairs = 64;                  // pairs staged per block pass
 constexpr int kPolyStride = 2 * C2D_POLY_KMAX;  // vertices per pair slot (A then B)
+constexpr int kPolyPitch = kPolyStride + 2;     // float2 per pair slot: 272 B = 17 x 16 B keeps b128 reads
+                                                // aligned and puts the two half-waves' rows on different banks
+
+C2D_DEV void minmax_update(float nx, float ny, float x, float y, float& mn, float& mx)
+{
+    const float p = nx * x + ny * y;  // unfused, reference utils.cu:173
+    mn = __builtin_fminf(mn, p);
+    mx = __builtin_fmaxf(mx, p);
+}
 
 __global__ __launch_bounds__(kBlock) void sat_poly_kernel(const float* __restrict__ vx, const float* __restrict__ vy,
                                                           const uint8_t* __restrict__ kcnt, size_t n,
                                                           uint8_t* __restrict__ out,
                                                           uint32_t* __restrict__ partial)
 {
-    // [pair][vertex] as float2; +1 float2 of padding per pair slot keeps the two
-    // half-waves (two different pairs) on different banks for the broadcast reads.
-    __shared__ float2 s_v[kPolyPairs][kPolyStride + 1];
+    __shared__ __attribute__((aligned(16))) float2 s_v[kPolyPairs][kPolyPitch];
     __shared__ uint8_t s_k[2][kPolyPairs];
     uint32_t my_count = 0;
     const int tid = threadIdx.x;
@@ -182,13 +193,12 @@ __global__ __launch_bounds__(kBlock) void sat_poly_kernel(const float* __restric
             const int j = tid & (kPolyPairs - 1);
             for (int row = tid / kPolyPairs; row < kPolyStride; row += kBlock / kPolyPairs) {
                 const int p = row / C2D_POLY_KMAX, v = row % C2D_POLY_KMAX;
-                float2 val = make_float2(0.f, 0.f);
-                if (j < pairs_here && v < (int)s_k[p][j]) {
-                    const size_t idx = ((size_t)p * C2D_POLY_KMAX + v) * n + base + j;
-                    val.x = vx[idx];
-                    val.y = vy[idx];
+                const int kp = (int)s_k[p][j];
+                if (j < pairs_here && v < ((kp + 1) & ~1)) {       // the vertices and one pad slot
+                    const int vv = v < kp ? v : kp - 1;            // pad = copy of the last vertex
+                    const size_t idx = ((size_t)p * C2D_POLY_KMAX + vv) * n + base + j;
+                    s_v[j][row] = make_float2(vx[idx], vy[idx]);
                 }
-                s_v[j][row] = val;
             }
         }
         __syncthreads();
@@ -209,24 +219,18 @@ __global__ __launch_bounds__(kBlock) void sat_poly_kernel(const float* __restric
                 const float2 e0 = Pn[i], e1 = Pn[i1];
                 const float ex = e1.x - e0.x, ey = e1.y - e0.y;
                 const float nx = -ey, ny = ex;
-                float min1, max1, min2, max2;
-                {
-                    float2 q = A[0];
-                    min1 = max1 = nx * q.x + ny * q.y;
-                    for (int k = 1; k < ka; k++) {
-                        q = A[k];
-                        float p = nx * q.x + ny * q.y;
-                        min1 = p < min1 ? p : min1;
-                        max1 = max1 < p ? p : max1;
-                    }
-                    q = B[0];
-                    min2 = max2 = nx * q.x + ny * q.y;
-                    for (int k = 1; k < kb; k++) {
-                        q = B[k];
-                        float p = nx * q.x + ny * q.y;
-                        min2 = p < min2 ? p : min2;
-                        max2 = max2 < p ? p : max2;
-                    }
+                float min1 = __builtin_inff(), max1 = -__builtin_inff(), min2 = __builtin_inff(), max2 = -__builtin_inff();
+                const float4* A4 = reinterpret_cast<const float4*>(A);
+                const float4* B4 = reinterpret_cast<const float4*>(B);
+                for (int k = 0; 2 * k < ka; k++) {
+                    const float4 q = A4[k];
+                    minmax_update(nx, ny, q.x, q.y, min1, max1);
+                    minmax_update(nx, ny, q.z, q.w, min1, max1);
+                }
+                for (int k = 0; 2 * k < kb; k++) {
+                    const float4 q = B4[k];
+                    minmax_update(nx, ny, q.x, q.y, min2, max2);
+                    minmax_update(nx, ny, q.z, q.w, min2, max2);
                 }
                 sep = (max1 < min2) || (max2 < min1);
             }
