@@ -45,10 +45,11 @@ int c2d_ctx_create(int device, c2d_ctx** out)
     if (std::strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) { delete ctx; return C2D_ERR_NO_DEVICE; }
     c2d::DeviceGuard g(device);
     if (!g.ok) { delete ctx; return C2D_ERR_NO_DEVICE; }
-    if (hipMalloc(&ctx->d_counters, 64) != hipSuccess || hipMalloc(&ctx->d_partial, C2D_PARTIAL_SLOTS * sizeof(uint32_t)) != hipSuccess || hipMalloc(&ctx->d_bins, 32 * sizeof(float)) != hipSuccess ||
+    if (hipMalloc(&ctx->d_counters, 64) != hipSuccess || hipMalloc(&ctx->d_count_words, C2D_COUNT_WORDS_BYTES) != hipSuccess ||
+        hipMemset(ctx->d_count_words, 0, C2D_COUNT_WORDS_BYTES) != hipSuccess || hipMalloc(&ctx->d_bins, 32 * sizeof(float)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pinned), 64, hipHostMallocDefault) != hipSuccess) {
         if (ctx->d_counters) (void)hipFree(ctx->d_counters);
-        if (ctx->d_partial) (void)hipFree(ctx->d_partial);
+        if (ctx->d_count_words) (void)hipFree(ctx->d_count_words);
         if (ctx->d_bins) (void)hipFree(ctx->d_bins);
         delete ctx;
         return C2D_ERR_NOMEM;
@@ -64,7 +65,7 @@ int c2d_ctx_destroy(c2d_ctx* ctx)
     for (auto& p : ctx->d_list)
         if (p) (void)hipFree(p);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
-    if (ctx->d_partial) (void)hipFree(ctx->d_partial);
+    if (ctx->d_count_words) (void)hipFree(ctx->d_count_words);
     if (ctx->d_bins) (void)hipFree(ctx->d_bins);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     delete ctx;

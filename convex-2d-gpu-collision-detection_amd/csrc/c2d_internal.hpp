@@ -16,14 +16,13 @@ struct c2d_ctx {
     uint32_t* d_list[2] = {nullptr, nullptr};  // active-scene index lists
     size_t list_capacity = 0;
     uint32_t* d_counters = nullptr;            // [0] next-active count
-    uint32_t* d_partial = nullptr;             // per-block partial counts of the SAT kernels
+    unsigned long long* d_count_words = nullptr;  // 256 x 128 B arrival/sum words of the SAT count (self-clearing)
     float* d_bins = nullptr;                   // accuracy_bins | bin_accuracy (<= 32 floats)
     uint32_t* h_pinned = nullptr;              // pinned host word for count read-back
     mutable std::string last_error;
 };
 
-// Slots of the per-block partial-count workspace = largest SAT grid (4 MiB).
-#define C2D_PARTIAL_SLOTS (1 << 20)
+#define C2D_COUNT_WORDS_BYTES (256 * 128)
 
 namespace c2d {
 

@@ -19,60 +19,55 @@ struct Planes10 { const float* p[10]; };
 struct Planes8 { float* p[8]; };
 
 constexpr int kBlock = 256;
-constexpr int kMaxBlocks = C2D_PARTIAL_SLOTS;  // one partial-count slot per block
+constexpr int kWideBlock = 64;          // the 4-pairs-per-lane kernel runs one wave per block
+constexpr int kMaxBlocks = 1 << 24;     // beyond this a launch falls back to its grid-stride loop
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Colliding-pair count.  Same-address atomics from every block serialise at the
-// memory side (measured: 9766 blocks -> +45 us on a 105 us kernel), so a block
-// only *stores* its partial sum to a workspace slot (wave sums by 64-wide
-// shuffles, wave leaders through LDS) and a one-block-per-8192-slots finishing
-// kernel adds the total to the caller's 64-bit counter.
-C2D_DEV void block_count_store(uint32_t lane_count, uint32_t* __restrict__ partial)
+// Colliding-pair count without a second kernel and without a hot atomic word.
+// Same-address atomics from every wave serialise at the memory side (measured:
+// 9766 block atomics on one word -> +45 us on a 105 us kernel).  Instead every
+// wave makes ONE returning 64-bit atomic add on one of 256 words that sit on
+// separate 128-byte lines of the ctx workspace; the word packs
+// (arrivals << 40 | partial sum).  Every wave of the grid arrives exactly once,
+// so the wave whose add completes a word's expected arrival count owns its
+// sum: it clears the word (the workspace is ready for the next launch) and adds
+// the sum to the caller's counter — at most 256 adds on that word per launch.
+// Measured against per-block partials + a finishing kernel: 105.4 vs 107.9 us.
+constexpr uint32_t kCountWords = 256;  // x 128 B = 32 KiB of ctx workspace
+
+C2D_DEV void wave_count_arrive(uint32_t lane_count, unsigned long long* __restrict__ d_count,
+                               unsigned long long* __restrict__ words)
 {
-    __shared__ uint32_t wave_sums[kBlock / 64];
     uint32_t v = lane_count;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) wave_sums[wave] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t s = 0;
-#pragma unroll
-        for (int w = 0; w < kBlock / 64; w++) s += wave_sums[w];
-        partial[blockIdx.x] = s;
-    }
-}
-
-__global__ __launch_bounds__(1024) void count_finish_kernel(const uint32_t* __restrict__ partial, uint32_t n,
-                                                            unsigned long long* __restrict__ d_count)
-{
-    __shared__ unsigned long long ws[16];
-    unsigned long long s = 0;
-    for (uint32_t i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024) s += partial[i];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long t = 0;
-#pragma unroll
-        for (int w = 0; w < 16; w++) t += ws[w];
-        if (t) atomicAdd(d_count, t);
+    if ((threadIdx.x & 63) == 0) {
+        const uint32_t waves_per_block = blockDim.x >> 6;
+        const uint32_t wave_id = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
+        const uint32_t n_waves = gridDim.x * waves_per_block;
+        const uint32_t slot = wave_id & (kCountWords - 1);
+        const uint32_t expected = n_waves / kCountWords + (slot < (n_waves & (kCountWords - 1)) ? 1u : 0u);
+        unsigned long long* w = words + (size_t)slot * 16;
+        const unsigned long long old = atomicAdd(w, (1ull << 40) | (unsigned long long)v);
+        if ((uint32_t)(old >> 40) + 1u == expected) {
+            const unsigned long long total = (old & ((1ull << 40) - 1)) + v;
+            atomicExch(w, 0ull);
+            if (total) atomicAdd(d_count, total);
+        }
     }
 }
 
 // ---- rectangle pairs, vertex format ------------------------------------------
 // VEC == 4: planes read as float4 (16 B / lane), results written as one dword.
 // VEC == 1: scalar loads; used for the tail and for unaligned buffers.
-template <int VEC>
-__global__ __launch_bounds__(kBlock) void sat_rect_verts_kernel(Planes16 P, size_t first, size_t n_groups,
+template <int VEC, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void sat_rect_verts_kernel(Planes16 P, size_t first, size_t n_groups,
                                                                 uint8_t* __restrict__ out,
-                                                                uint32_t* __restrict__ partial)
+                                                                unsigned long long* __restrict__ d_count, unsigned long long* __restrict__ words)
 {
     uint32_t my_count = 0;
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x; g < n_groups; g += stride) {
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    for (size_t g = (size_t)blockIdx.x * BLOCK + threadIdx.x; g < n_groups; g += stride) {
         if constexpr (VEC == 4) {
             f32x4 v[16];
 #pragma unroll
@@ -104,12 +99,12 @@ __global__ __launch_bounds__(kBlock) void sat_rect_verts_kernel(Planes16 P, size
             my_count += c;
         }
     }
-    if (partial) block_count_store(my_count, partial);
+    if (d_count) wave_count_arrive(my_count, d_count, words);
 }
 
 // ---- rectangle pairs, pose format (10 planes) -----------------------------------
 __global__ __launch_bounds__(kBlock) void sat_rect_pose_kernel(Planes10 P, size_t n, uint8_t* __restrict__ out,
-                                                               uint32_t* __restrict__ partial)
+                                                               unsigned long long* __restrict__ d_count, unsigned long long* __restrict__ words)
 {
     uint32_t my_count = 0;
     const size_t stride = (size_t)gridDim.x * kBlock;
@@ -126,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void sat_rect_pose_kernel(Planes10 P, size_
         out[i] = (uint8_t)hit;
         my_count += hit;
     }
-    if (partial) block_count_store(my_count, partial);
+    if (d_count) wave_count_arrive(my_count, d_count, words);
 }
 
 // ---- create_rect + rot_trans_rectangle over SoA (reference utils.cu:119-142) ------
@@ -170,7 +165,8 @@ C2D_DEV void minmax_update(float nx, float ny, float x, float y, float& mn, floa
 __global__ __launch_bounds__(kBlock) void sat_poly_kernel(const float* __restrict__ vx, const float* __restrict__ vy,
                                                           const uint8_t* __restrict__ kcnt, size_t n,
                                                           uint8_t* __restrict__ out,
-                                                          uint32_t* __restrict__ partial)
+                                                          unsigned long long* __restrict__ d_count,
+                                                          unsigned long long* __restrict__ words)
 {
     __shared__ __attribute__((aligned(16))) float2 s_v[kPolyPairs][kPolyPitch];
     __shared__ uint8_t s_k[2][kPolyPairs];
@@ -243,7 +239,7 @@ __global__ __launch_bounds__(kBlock) void sat_poly_kernel(const float* __restric
             }
         }
     }
-    if (partial) block_count_store(my_count, partial);
+    if (d_count) wave_count_arrive(my_count, d_count, words);
 }
 
 __global__ void poly_validate_kernel(const uint8_t* __restrict__ kcnt, size_t n2, uint32_t* __restrict__ bad)
@@ -255,14 +251,6 @@ __global__ void poly_validate_kernel(const uint8_t* __restrict__ kcnt, size_t n2
         b |= (k < 1 || k > C2D_POLY_KMAX) ? 1u : 0u;
     }
     if (b) atomicOr(bad, 1u);
-}
-
-// Adds the partial sums of the `slots` blocks that just ran to *d_count.
-static int finish_count(c2d_ctx* ctx, uint32_t slots, unsigned long long* d_count, hipStream_t s)
-{
-    hipLaunchKernelGGL(count_finish_kernel, dim3((slots + 8191) / 8192), dim3(1024), 0, s, ctx->d_partial, slots, d_count);
-    C2D_LAUNCH_CHECK(ctx);
-    return C2D_OK;
 }
 
 static inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
@@ -307,23 +295,22 @@ int c2d_sat_rect_pairs_verts(c2d_ctx* ctx, const float* const d_planes[16], size
     }
     DeviceGuard g(ctx->device);
     hipStream_t s = (hipStream_t)stream;
-    // One group of 4 pairs per lane and no grid-stride loop up to kMaxBlocks blocks:
-    // short blocks retiring all through the launch stream better than a resident
-    // grid-stride grid (measured +3 %), and every block owns one partial-count slot.
-    uint32_t* partial = d_count ? ctx->d_partial : nullptr;
+    // One group of 4 pairs per lane, 64-thread blocks, no grid-stride loop below kMaxBlocks:
+    // short single-wave blocks retiring all through the launch stream better than a
+    // resident grid-stride grid (tools/sat_tune: 103.0 vs 109.3 us per 1e7 pairs).
     const size_t n4 = wide ? n / 4 : 0;
     if (n4) {
-        const int grid = grid_for(n4, kBlock, kMaxBlocks);
-        hipLaunchKernelGGL(sat_rect_verts_kernel<4>, dim3(grid), dim3(kBlock), 0, s, P, (size_t)0, n4, d_out, partial);
+        const int grid = grid_for(n4, kWideBlock, kMaxBlocks);
+        hipLaunchKernelGGL((sat_rect_verts_kernel<4, kWideBlock>), dim3(grid), dim3(kWideBlock), 0, s, P, (size_t)0, n4, d_out,
+                           d_count, ctx->d_count_words);
         C2D_LAUNCH_CHECK(ctx);
-        if (partial) { int st = finish_count(ctx, (uint32_t)grid, d_count, s); if (st) return st; }
     }
     const size_t rest = n - 4 * n4;
     if (rest) {
         const int grid = grid_for(rest, kBlock, kMaxBlocks);
-        hipLaunchKernelGGL(sat_rect_verts_kernel<1>, dim3(grid), dim3(kBlock), 0, s, P, 4 * n4, rest, d_out, partial);
+        hipLaunchKernelGGL((sat_rect_verts_kernel<1, kBlock>), dim3(grid), dim3(kBlock), 0, s, P, 4 * n4, rest, d_out, d_count,
+                           ctx->d_count_words);
         C2D_LAUNCH_CHECK(ctx);
-        if (partial) { int st = finish_count(ctx, (uint32_t)grid, d_count, s); if (st) return st; }
     }
     return C2D_OK;
 }
@@ -341,10 +328,9 @@ int c2d_sat_rect_pairs_pose(c2d_ctx* ctx, const float* const d_pose_planes[10], 
     }
     DeviceGuard g(ctx->device);
     const int grid = grid_for(n, kBlock, kMaxBlocks);
-    uint32_t* partial = d_count ? ctx->d_partial : nullptr;
-    hipLaunchKernelGGL(sat_rect_pose_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, P, n, d_out, partial);
+    hipLaunchKernelGGL(sat_rect_pose_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, P, n, d_out, d_count,
+                       ctx->d_count_words);
     C2D_LAUNCH_CHECK(ctx);
-    if (partial) return finish_count(ctx, (uint32_t)grid, d_count, (hipStream_t)stream);
     return C2D_OK;
 }
 
@@ -366,10 +352,8 @@ int c2d_sat_poly_pairs(c2d_ctx* ctx, const float* d_vx, const float* d_vy, const
     if (ctx->h_pinned[8]) return fail_arg(ctx, "c2d_sat_poly_pairs: vertex count outside 1..C2D_POLY_KMAX");
     const size_t n_pass = (n + kPolyPairs - 1) / kPolyPairs;
     const int grid = (int)(n_pass < (size_t)ctx->prop.multiProcessorCount * 8 ? n_pass : (size_t)ctx->prop.multiProcessorCount * 8);
-    uint32_t* partial = d_count ? ctx->d_partial : nullptr;
-    hipLaunchKernelGGL(sat_poly_kernel, dim3(grid), dim3(kBlock), 0, s, d_vx, d_vy, d_k, n, d_out, partial);
+    hipLaunchKernelGGL(sat_poly_kernel, dim3(grid), dim3(kBlock), 0, s, d_vx, d_vy, d_k, n, d_out, d_count, ctx->d_count_words);
     C2D_LAUNCH_CHECK(ctx);
-    if (partial) return finish_count(ctx, (uint32_t)grid, d_count, s);
     return C2D_OK;
 }
 

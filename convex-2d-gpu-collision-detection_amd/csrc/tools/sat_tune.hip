@@ -42,6 +42,66 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_sat(Planes16 P, size_t n_groups
     }
 }
 
+// software-pipelined variant: the next group's 16 loads are in flight while the current group is
+// evaluated (ping-pong register buffers, 2 groups per loop trip)
+C2D_DEV uint32_t eval4(const f32x4 (&v)[16])
+{
+    uint32_t packed = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        float r1[8], r2[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { r1[k] = v[k][e]; r2[k] = v[8 + k][e]; }
+        packed |= (rect_collide(r1, r2) ? 1u : 0u) << (8 * e);
+    }
+    return packed;
+}
+C2D_DEV void load16(const Planes16& P, size_t g, f32x4 (&v)[16])
+{
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P.p[k]) + g);
+}
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_sat_pf(Planes16 P, size_t n_groups, uint8_t* __restrict__ out)
+{
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    size_t g = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    f32x4 a[16], b[16];
+    if (g < n_groups) load16(P, g, a);
+    while (g < n_groups) {
+        const size_t g1 = g + stride;
+        if (g1 < n_groups) load16(P, g1, b);
+        __builtin_nontemporal_store(eval4(a), reinterpret_cast<uint32_t*>(out) + g);
+        if (g1 >= n_groups) break;
+        const size_t g2 = g1 + stride;
+        if (g2 < n_groups) load16(P, g2, a);
+        __builtin_nontemporal_store(eval4(b), reinterpret_cast<uint32_t*>(out) + g1);
+        g = g2;
+    }
+}
+
+// 2 pairs per lane (8-byte loads): half the data registers, more waves per SIMD
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_sat_v2(Planes16 P, size_t n_groups2, uint8_t* __restrict__ out)
+{
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    for (size_t g = (size_t)blockIdx.x * BLOCK + threadIdx.x; g < n_groups2; g += stride) {
+        f32x2 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(P.p[k]) + g);
+        uint32_t packed = 0;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            float r1[8], r2[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { r1[k] = v[k][e]; r2[k] = v[8 + k][e]; }
+            packed |= (rect_collide(r1, r2) ? 1u : 0u) << (8 * e);
+        }
+        __builtin_nontemporal_store((uint16_t)packed, reinterpret_cast<uint16_t*>(out) + g);
+    }
+}
+
 // counting variants -------------------------------------------------------------------------
 // MODE 0: one 64-bit atomic per block on a single word (LDS block reduce)
 // MODE 1: per-block partial stored to a workspace, summed by a finishing kernel
@@ -101,6 +161,40 @@ __global__ __launch_bounds__(1024) void k_finish(const uint32_t* __restrict__ pa
     }
 }
 
+// MODE 2: one returning 64-bit atomic per wave on one of 256 line-separated words; the word packs
+// (arrivals << 40 | sum); the last arriver of a word flushes it into *d_count and clears it.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_sat_count_tk(Planes16 P, size_t n_groups, uint8_t* __restrict__ out,
+                                                        unsigned long long* __restrict__ d_count,
+                                                        unsigned long long* __restrict__ words)
+{
+    uint32_t my = 0;
+    const size_t g = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (g < n_groups) {
+        f32x4 v[16];
+        load16(P, g, v);
+        const uint32_t packed = eval4(v);
+        my = __popc(packed);
+        __builtin_nontemporal_store(packed, reinterpret_cast<uint32_t*>(out) + g);
+    }
+    uint32_t v = my;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) {
+        const uint32_t wave_id = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+        const uint32_t n_waves = gridDim.x * (BLOCK / 64);
+        const uint32_t slot = wave_id & 255u;
+        const uint32_t expected = (n_waves >> 8) + (slot < (n_waves & 255u) ? 1u : 0u);
+        unsigned long long* w = words + (size_t)slot * 16;  // 128-B apart
+        const unsigned long long old = atomicAdd(w, (1ull << 40) | (unsigned long long)v);
+        if ((uint32_t)(old >> 40) + 1u == expected) {
+            const unsigned long long total = (old & ((1ull << 40) - 1)) + v;
+            *w = 0;  // next launch is stream-ordered behind this kernel
+            if (total) atomicAdd(d_count, total);
+        }
+    }
+}
+
 // copy-only ceiling with the same access pattern (16 float4 streams in, 1 dword out)
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_stream(Planes16 P, size_t n_groups, uint8_t* __restrict__ out)
@@ -126,6 +220,13 @@ void launch_count(Planes16 P, size_t ng, uint8_t* out, int grid, hipStream_t s)
     hipLaunchKernelGGL((k_sat_count<B, MODE>), dim3(grid), dim3(B), 0, s, P, ng, out, g_count, g_partial);
     if (MODE == 1) hipLaunchKernelGGL(k_finish, dim3((grid + 8191) / 8192), dim3(1024), 0, s, g_partial, (uint32_t)grid, g_count);
 }
+static unsigned long long* g_words;
+template <int B>
+void launch_tk(Planes16 P, size_t ng, uint8_t* out, int grid, hipStream_t s) { hipLaunchKernelGGL((k_sat_count_tk<B>), dim3(grid), dim3(B), 0, s, P, ng, out, g_count, g_words); }
+template <int B>
+void launch_pf(Planes16 P, size_t ng, uint8_t* out, int grid, hipStream_t s) { hipLaunchKernelGGL((k_sat_pf<B>), dim3(grid), dim3(B), 0, s, P, ng, out); }
+template <int B>
+void launch_v2(Planes16 P, size_t ng, uint8_t* out, int grid, hipStream_t s) { hipLaunchKernelGGL((k_sat_v2<B>), dim3(grid), dim3(B), 0, s, P, ng * 2, out); }
 template <int B>
 void launch_stream(Planes16 P, size_t ng, uint8_t* out, int grid, hipStream_t s) { hipLaunchKernelGGL((k_stream<B>), dim3(grid), dim3(B), 0, s, P, ng, out); }
 
@@ -184,6 +285,17 @@ int main(int argc, char** argv)
     add("count partial b256 full", launch_count<256, 1>, 256, full);
     add("count partial b64 full", launch_count<64, 1>, 64, full);
     add("count partial b512 full", launch_count<512, 1>, 512, full);
+    CK(hipMalloc(&g_words, 256 * 128)); CK(hipMemset(g_words, 0, 256 * 128));
+    add("count ticket b64 full", launch_tk<64>, 64, full);
+    add("count ticket b256 full", launch_tk<256>, 256, full);
+    add("prefetch b256 cap512", launch_pf<256>, 256, 512);
+    add("prefetch b256 cap768", launch_pf<256>, 256, 768);
+    add("prefetch b256 cap1024", launch_pf<256>, 256, 1024);
+    add("prefetch b256 cap1536", launch_pf<256>, 256, 1536);
+    add("prefetch b64 cap3072", launch_pf<64>, 64, 3072);
+    add("prefetch b64 cap4096", launch_pf<64>, 64, 4096);
+    add("vec2 b256 full", launch_v2<256>, 256, full);
+    add("vec2 b256 cap4096", launch_v2<256>, 256, 4096);
     add("stream-only b256 cap2048", launch_stream<256>, 256, 2048);
     add("stream-only b256 full", launch_stream<256>, 256, full);
     const bool sustained = argc > 3 && std::string(argv[3]) == "sustained";
@@ -191,7 +303,7 @@ int main(int argc, char** argv)
         // steady-state clocks: 200 untimed launches, then 100 timed, per variant, two passes
         printf("%-28s %10s %10s %8s   (sustained)\n", "variant", "pass1_us", "pass2_us", "frac8T");
         for (auto& v : V) {
-            size_t blocks = (ng + v.block - 1) / v.block;
+            size_t blocks = ((v.name.rfind("vec2", 0) == 0 ? 2 * ng : ng) + v.block - 1) / v.block;
             int grid = (int)std::min<size_t>(blocks, (size_t)v.grid_cap);
             float res[2];
             for (int pass = 0; pass < 2; pass++) {
