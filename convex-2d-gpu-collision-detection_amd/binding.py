@@ -60,7 +60,8 @@ class _McScenesArgs(C.Structure):
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, "lib", "libc2d.so")
+    """lib/libc2d.so next to this file; C2D_LIBRARY overrides it (to try another build of the same C-ABI)."""
+    return os.environ.get("C2D_LIBRARY") or os.path.join(_HERE, "lib", "libc2d.so")
 
 
 _lib: Optional[C.CDLL] = None
@@ -87,6 +88,7 @@ _SIGNATURES = {
     "c2d_sat_rect_pairs_pose": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "c2d_sat_poly_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "c2d_philox_normals": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "c2d_math_eval": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "c2d_mc_pair": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.POINTER(_Position), C.POINTER(_Pose), C.POINTER(_StdDev),
                               C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
     "c2d_mc_scenes": (C.c_int, [C.c_void_p, C.POINTER(_McScenesArgs), C.c_void_p]),
@@ -264,6 +266,12 @@ class Engine:
     def philox_normals(self, seed: int, scene_id: int, sample_begin: int, n: int, normals, raw=None, stream: int = 0):
         self._check(self.lib.c2d_philox_normals(self.h, seed, scene_id, sample_begin, n, _ptr_of(normals), _ptr_of(raw),
                                                 C.c_void_p(stream)), "c2d_philox_normals")
+
+    MATH_LOG, MATH_SINCOS, MATH_SINCOS_U32, MATH_SQRT, MATH_BOX_MULLER = range(5)
+
+    def math_eval(self, fn: int, in_bits, n: int, out0, out1=None, stream: int = 0):
+        self._check(self.lib.c2d_math_eval(self.h, fn, _ptr_of(in_bits), n, _ptr_of(out0), _ptr_of(out1), C.c_void_p(stream)),
+                    "c2d_math_eval")
 
     def mc_pair(self, robot_w, robot_h, pos, pose, std_dev, seed, scene_id, sample_begin, n_samples, hits, stream: int = 0):
         self._check(self.lib.c2d_mc_pair(self.h, robot_w, robot_h, C.byref(_Position(*pos)), C.byref(_Pose(*pose)),

@@ -40,6 +40,24 @@ C2D_DEV float log_(float u)
     return fma_((float)e, 0x1.62e430p-1f, r);
 }
 
+// ---- correctly rounded sqrt for x in {+-0} U [2^-96, 2^96] ----------------------------------
+// hipcc's own correctly rounded sqrtf is this refinement wrapped in denormal scaling and an
+// inf/nan fix-up (16 instructions); the Box-Muller radius argument -2*log(u) never needs
+// either (it is -0 or within [1.1e-7, 46]), so only the refinement is kept (9 instructions):
+// v_sqrt_f32 is within 1 ulp, the two fma residuals pick the neighbour that rounds correctly.
+// Bit-equal to IEEE sqrtf on that domain (exhaustive two-binade test in tests/test_gpu_mc.py).
+C2D_DEV float sqrt_normal_range(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u);
+    const float s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = fma_(-s_dn, s, x);
+    const float r_up = fma_(-s_up, s, x);
+    float r = r_dn <= 0.0f ? s_dn : s;
+    r = r_up > 0.0f ? s_up : r;
+    return r;
+}
+
 // (sn, cs) of the first quadrant -> quadrant q (angle + q*pi/2)
 C2D_DEV void quadrant_rotate(int q, float sn, float cs, float& s_out, float& c_out)
 {
@@ -133,7 +151,7 @@ C2D_DEV U4 philox_block(uint64_t seed, uint64_t scene, uint64_t sample, uint32_t
 C2D_DEV void box_muller(uint32_t x, uint32_t y, float& n0, float& n1)
 {
     float u = fma_((float)x, 0x1p-32f, 0x1p-33f);
-    float rad = __builtin_sqrtf(-2.0f * log_(u));
+    float rad = sqrt_normal_range(-2.0f * log_(u));
     float sn, cs;
     sincos_u32(y, sn, cs);
     n0 = sn * rad;

@@ -67,24 +67,30 @@ C2D_DEV void sample_obstacle(const Scene& sc, uint64_t seed, uint64_t scene_id, 
 }
 
 // convex_collide(robot, obstacle) (utils.cu:159-184).  All eight axes are part
-// of the result; the obstacle's four axes are skipped only when every lane of
-// the wave is already separated, which cannot change any lane's answer.
+// of the result; the remaining axes are skipped only when every lane of the
+// wave is already separated, which cannot change any lane's answer.  The
+// wave-wide check (one ballot + scalar branch) sits after axes 2, 4 and 6: far
+// scenes (p ~ 0, the bulk of an adaptive run's samples) leave after two robot
+// axes, near scenes pay three scalar branches.
+#ifndef C2D_MC_EARLY_MASK
+#define C2D_MC_EARLY_MASK 0x2A  // bit i set: check after axis i+1 (axes 0-3 robot, 4-7 obstacle)
+#endif
 C2D_DEV bool sample_collides(const Scene& sc, const float (&o)[8])
 {
     bool sep = false;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        float ax = sc.robot[(2 * i + 2) & 7] - sc.robot[2 * i];
-        float ay = sc.robot[(2 * i + 3) & 7] - sc.robot[2 * i + 1];
-        sep |= axis_separates(ax, ay, sc.robot, o);
-    }
-    if (__ballot(!sep) != 0ull) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            float ax = o[(2 * i + 2) & 7] - o[2 * i];
-            float ay = o[(2 * i + 3) & 7] - o[2 * i + 1];
-            sep |= axis_separates(ax, ay, sc.robot, o);
+    for (int i = 0; i < 8; i++) {
+        float ax, ay;
+        if (i < 4) {
+            ax = sc.robot[(2 * i + 2) & 7] - sc.robot[2 * i];
+            ay = sc.robot[(2 * i + 3) & 7] - sc.robot[2 * i + 1];
+        } else {
+            const int j = i - 4;
+            ax = o[(2 * j + 2) & 7] - o[2 * j];
+            ay = o[(2 * j + 3) & 7] - o[2 * j + 1];
         }
+        sep |= axis_separates(ax, ay, sc.robot, o);
+        if (((C2D_MC_EARLY_MASK >> i) & 1) && __ballot(!sep) == 0ull) return false;
     }
     return !sep;
 }
@@ -266,6 +272,28 @@ __global__ void philox_normals_kernel(uint64_t seed, uint64_t scene_id, uint64_t
     }
 }
 
+// ---- canonical-math parity hook -------------------------------------------------------------
+__global__ void math_eval_kernel(int fn, const uint32_t* __restrict__ in, size_t n, float* __restrict__ out0,
+                                 float* __restrict__ out1)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t bits = in[i];
+        const float x = __uint_as_float(bits);
+        float a = 0.0f, b = 0.0f;
+        switch (fn) {
+        case C2D_MATH_LOG: a = log_(x); break;
+        case C2D_MATH_SINCOS: sincos_(x, a, b); break;
+        case C2D_MATH_SINCOS_U32: sincos_u32(bits, a, b); break;
+        case C2D_MATH_SQRT: a = sqrt_normal_range(x); break;
+        case C2D_MATH_BOX_MULLER: box_muller(bits, ~bits * 2654435761u, a, b); break;
+        default: break;
+        }
+        out0[i] = a;
+        if (out1) out1[i] = b;
+    }
+}
+
 // ---- scene sampler (reference generate_dataset.cu:207-219) ------------------------------
 constexpr uint64_t kSceneDomain = 0x5ce9e5a3c0117de5ull;
 
@@ -305,6 +333,18 @@ __global__ void sample_scenes_kernel(const Pose* __restrict__ poses, uint32_t nu
 using namespace c2d;
 
 extern "C" {
+
+int c2d_math_eval(c2d_ctx* ctx, int fn, const uint32_t* d_in_bits, size_t n, float* d_out0, float* d_out1, c2d_stream stream)
+{
+    if (!ctx) return C2D_ERR_INVALID_ARG;
+    if (n == 0) return C2D_OK;
+    if (!d_in_bits || !d_out0 || fn < C2D_MATH_LOG || fn > C2D_MATH_BOX_MULLER) return fail_arg(ctx, "c2d_math_eval: bad argument");
+    DeviceGuard g(ctx->device);
+    hipLaunchKernelGGL(math_eval_kernel, dim3(grid_for(n, 256, ctx->prop.multiProcessorCount * 8)), dim3(256), 0,
+                       (hipStream_t)stream, fn, d_in_bits, n, d_out0, d_out1);
+    C2D_LAUNCH_CHECK(ctx);
+    return C2D_OK;
+}
 
 int c2d_philox_normals(c2d_ctx* ctx, uint64_t seed, uint64_t scene_id, uint64_t sample_begin, size_t n,
                        float* d_normals, uint32_t* d_raw, c2d_stream stream)

@@ -156,6 +156,22 @@ int c2d_sat_poly_pairs(c2d_ctx* ctx, const float* d_vx, const float* d_vy, const
 int c2d_philox_normals(c2d_ctx* ctx, uint64_t seed, uint64_t scene_id, uint64_t sample_begin,
                        size_t n, float* d_normals, uint32_t* d_raw, c2d_stream stream);
 
+/* c2d_math_eval (parity/debug): evaluates one canonical math function of the
+ * arithmetic contract on n inputs given as raw 32-bit patterns, so that tests
+ * can compare the device implementation with the oracle bit for bit.
+ *   C2D_MATH_LOG        out0 = log(x)                 x = float(bits) > 0, normal
+ *   C2D_MATH_SINCOS     out0, out1 = sin(x), cos(x)   stands in for utils.cu:133-134
+ *   C2D_MATH_SINCOS_U32 out0, out1 = sin, cos of 2*pi*bits/2^32
+ *   C2D_MATH_SQRT       out0 = correctly rounded sqrt(x), x in {+-0} U [2^-96, 2^96]
+ *   C2D_MATH_BOX_MULLER out0, out1 = the two normals of words (bits, ~bits * 2654435761) */
+#define C2D_MATH_LOG 0
+#define C2D_MATH_SINCOS 1
+#define C2D_MATH_SINCOS_U32 2
+#define C2D_MATH_SQRT 3
+#define C2D_MATH_BOX_MULLER 4
+int c2d_math_eval(c2d_ctx* ctx, int fn, const uint32_t* d_in_bits, size_t n, float* d_out0,
+                  float* d_out1, c2d_stream stream);
+
 /* ---- Monte-Carlo collision probability ---------------------------------------
  *
  * c2d_mc_pair: one scene, sample-parallel.  Replaces the body of

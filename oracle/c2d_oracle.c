@@ -550,3 +550,25 @@ void c2d_oracle_sample_scenes(const Pose* poses, uint32_t num_poses, const StdDe
         scenes[g].pose_idx = (float)pose_idx;
     }
 }
+
+/* ------------------------------------------------------------------------ */
+/* Array forms of the canonical math (parity checks against c2d_math_eval)   */
+/* ------------------------------------------------------------------------ */
+void c2d_oracle_math_eval(int fn, const uint32_t* in_bits, size_t n, float* out0, float* out1)
+{
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)n; i++) {
+        uint32_t bits = in_bits[i];
+        float x = u2f(bits), a = 0.0f, b = 0.0f;
+        switch (fn) {
+        case 0: a = c2d_oracle_logf(x); break;
+        case 1: c2d_oracle_sincosf(x, &a, &b); break;
+        case 2: c2d_oracle_sincos_u32(bits, &a, &b); break;
+        case 3: a = sqrtf(x); break;
+        case 4: c2d_oracle_box_muller(bits, ~bits * 2654435761u, &a, &b); break;
+        default: break;
+        }
+        out0[i] = a;
+        if (out1) out1[i] = b;
+    }
+}

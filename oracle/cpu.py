@@ -255,3 +255,12 @@ def sample_scenes(poses, std_devs, robot_w, robot_h, spread, seed, scene_id_base
         C.c_uint32(len(std_devs)), C.c_float(robot_w), C.c_float(robot_h), C.c_float(spread),
         C.c_uint64(seed), C.c_uint64(scene_id_base), C.c_size_t(n), C.c_void_p(scenes.ctypes.data))
     return scenes
+
+
+def math_eval(fn: int, in_bits):
+    """Canonical math over an array of raw 32-bit inputs (fn as include/c2d.h C2D_MATH_*)."""
+    in_bits = np.ascontiguousarray(in_bits, dtype=np.uint32)
+    out0 = np.empty(in_bits.shape, np.float32)
+    out1 = np.empty(in_bits.shape, np.float32)
+    lib().c2d_oracle_math_eval(C.c_int(fn), _ptr(in_bits, C.c_uint32), C.c_size_t(in_bits.size), _ptr(out0), _ptr(out1))
+    return out0, out1

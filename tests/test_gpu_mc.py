@@ -37,6 +37,44 @@ def test_philox_stream_golden_and_oracle(eng, oracle):
     assert np.array_equal(d_n.get().view(np.uint32), oracle.normals5(99, 12345, 10**12, n).view(np.uint32))
 
 
+def _math_both(eng, oracle, fn, bits):
+    bits = np.ascontiguousarray(bits, dtype=np.uint32)
+    d_in = eng.to_device(bits)
+    d0, d1 = eng.empty(bits.size, np.float32), eng.empty(bits.size, np.float32)
+    eng.math_eval(fn, d_in, bits.size, d0, d1)
+    g0, g1 = d0.get(), d1.get()
+    for a in (d_in, d0, d1):
+        a.free()
+    r0, r1 = oracle.math_eval(fn, bits)
+    return g0.view(np.uint32), g1.view(np.uint32), r0.view(np.uint32), r1.view(np.uint32)
+
+
+def test_canonical_math_bit_exact(eng, oracle):
+    """Device canonical math == oracle, bit for bit, on dense input sweeps."""
+    rng = np.random.default_rng(3)
+    # sqrt: exhaustive over two binades [1, 4) (every mantissa, both exponent parities) + the Box-Muller range
+    bits = np.arange(0x3F800000, 0x40800000, dtype=np.uint32)
+    g0, _, r0, _ = _math_both(eng, oracle, eng.MATH_SQRT, bits)
+    assert np.array_equal(g0, r0)
+    x = np.concatenate([rng.uniform(1e-7, 50, 4_000_000), 10.0 ** rng.uniform(-25, 25, 1_000_000), [0.0, -0.0, 2.0**-96, 2.0**96]]).astype(np.float32)
+    g0, _, r0, _ = _math_both(eng, oracle, eng.MATH_SQRT, x.view(np.uint32))
+    assert np.array_equal(g0, r0)
+    # log on (0, 1] (the Box-Muller domain) and beyond
+    u = np.concatenate([rng.uniform(2.0**-33, 1, 4_000_000), 2.0 ** rng.uniform(-33, 0, 1_000_000), [2.0**-33, 1.0, 0.5, 2 / 3]]).astype(np.float32)
+    g0, _, r0, _ = _math_both(eng, oracle, eng.MATH_LOG, u.view(np.uint32))
+    assert np.array_equal(g0, r0)
+    # sin/cos of float angles incl. large ones, and of integer angles incl. octant boundaries
+    th = np.concatenate([rng.uniform(-10, 10, 4_000_000), rng.uniform(-1e5, 1e5, 1_000_000), [0.0, -0.0, np.pi / 4, np.pi / 2, np.pi]]).astype(np.float32)
+    g0, g1, r0, r1 = _math_both(eng, oracle, eng.MATH_SINCOS, th.view(np.uint32))
+    assert np.array_equal(g0, r0) and np.array_equal(g1, r1)
+    y = np.concatenate([rng.integers(0, 2**32, 5_000_000, dtype=np.uint64).astype(np.uint32),
+                        np.array([0, 0x1FFFFFFF, 0x20000000, 0x20000001, 0x3FFFFFFF, 0x40000000, 0x7FFFFFFF, 0x80000000, 0xFFFFFFFF], np.uint32)])
+    g0, g1, r0, r1 = _math_both(eng, oracle, eng.MATH_SINCOS_U32, y)
+    assert np.array_equal(g0, r0) and np.array_equal(g1, r1)
+    g0, g1, r0, r1 = _math_both(eng, oracle, eng.MATH_BOX_MULLER, y)
+    assert np.array_equal(g0, r0) and np.array_equal(g1, r1)
+
+
 def test_mc_pair_golden_cases(eng):
     g = np.load(os.path.join(GOLD, "mc_pair_cases.npz"))
     rw, rh = (float(v) for v in g["robot"])
