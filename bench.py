@@ -80,6 +80,7 @@ def main() -> None:
                          "up to 12 %% slower while the power manager ramps clocks (profiles/r01a trace)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mc", action="store_true")
+    ap.add_argument("--no-pose", action="store_true")
     ap.add_argument("--scenes", type=int, default=4_000_000,
                     help="config 4 data points per GPU (1e6 scenes x 32 obstacle instances / 8 GPUs); 0 = skip the leg")
     ap.add_argument("--scenes-max-samples", type=int, default=120_000)
@@ -136,7 +137,7 @@ def main() -> None:
         eng.rects_from_poses(*[row(pose, 5 * r + k) for k in range(5)], n, [row(planes, 8 * r + k) for k in range(8)], stream=sh)
     plane_ptrs = [row(planes, k) for k in range(16)]
     torch.cuda.synchronize()
-    del pose
+    pose_ptrs = [row(pose, k) for k in range(10)]
 
     def step():
         eng.sat_rect_pairs_verts(plane_ptrs, n, out.data_ptr(), count.data_ptr(), stream=sh)
@@ -191,6 +192,29 @@ def main() -> None:
     roofline = {"bound": "hbm", "kernel": "sat_rect_verts_kernel<4>", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": BYTES_PER_PAIR * n, "kernel_ms": round(kernel_ms, 5)}
+
+    # ---- secondary input format: poses (41 B/pair), reported separately ----------
+    pose_leg = None
+    if not args.no_pose:
+        pcount = torch.zeros(1, dtype=torch.int64, device=dev)
+
+        def pose_step():
+            eng.sat_rect_pairs_pose(pose_ptrs, n, out.data_ptr(), pcount.data_ptr(), stream=sh)
+
+        prewarm(pose_step)
+        pe0, pe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        pe0.record(stream)
+        for _ in range(args.steps):
+            pose_step()
+        pe1.record(stream)
+        torch.cuda.synchronize()
+        pms = pe0.elapsed_time(pe1) / args.steps
+        pose_leg = {"metric": "sat_pair_tests_per_s (pose format, per GPU)", "value": n / (pms * 1e-3), "kernel_ms": round(pms, 5),
+                    "bytes_per_pair": 41, "achieved_GBs": round(41 * n / (pms * 1e-3) / 1e9, 1),
+                    "frac_of_hbm_peak": round(41 * n / (pms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "note": "rectangles rebuilt from (cx,cy,w,h,theta) per pair: ~400 VALU instr per 41 B, VALU and HBM both near their roofs"}
+    del pose
 
     # ---- Monte-Carlo leg: config 3 --------------------------------------------------------
     mc = None
@@ -342,7 +366,7 @@ def main() -> None:
             "config": {"workload": "config2: 1e7 random OBB pairs per GPU, 16 SoA vertex planes -> u8 booleans, single SAT overlap kernel",
                        "pairs_per_gpu": n, "bytes_per_pair": BYTES_PER_PAIR, "collide_rate": round(collide_rate, 5),
                        "parallelism": f"pairs sharded over {world} GPU(s), one RCCL all-reduce of the hit count"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "mc": mc, "scenes": scenes_leg, "poly": poly_leg,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "pose_format": pose_leg, "mc": mc, "scenes": scenes_leg, "poly": poly_leg,
             "device": eng.info()["name"],
         }
         print(json.dumps(line), flush=True)

@@ -54,6 +54,7 @@ class _McScenesArgs(C.Structure):
         ("accuracy_bins", C.POINTER(C.c_float)), ("bin_accuracy", C.POINTER(C.c_float)),
         ("n_accuracy_bins", C.c_uint32), ("max_samples", C.c_uint32),
         ("seed", C.c_uint64), ("scene_id_base", C.c_uint64),
+        ("schedule_small_batch", C.c_uint32), ("schedule_large_batch", C.c_uint32), ("schedule_switch_at", C.c_uint32),
         ("d_hits", C.c_void_p), ("d_n_used", C.c_void_p), ("d_rows", C.c_void_p),
         ("total_samples", C.POINTER(C.c_uint64)), ("iterations", C.POINTER(C.c_uint32)),
     ]
@@ -279,7 +280,8 @@ class Engine:
                                          _ptr_of(hits), C.c_void_p(stream)), "c2d_mc_pair")
 
     def mc_scenes(self, poses, num_poses, std_devs, num_std_devs, scenes, n_scenes, robot_w, robot_h, accuracy_bins,
-                  bin_accuracy, max_samples, seed, scene_id_base, hits, n_used, rows=None, stream: int = 0):
+                  bin_accuracy, max_samples, seed, scene_id_base, hits, n_used, rows=None, stream: int = 0,
+                  schedule=(0, 0, 0)):
         bins = np.ascontiguousarray(accuracy_bins, dtype=np.float32)
         acc = np.ascontiguousarray(bin_accuracy, dtype=np.float32)
         if len(acc) != len(bins) - 1:
@@ -287,7 +289,8 @@ class Engine:
         total, iters = C.c_uint64(0), C.c_uint32(0)
         a = _McScenesArgs(_ptr_of(poses), num_poses, _ptr_of(std_devs), num_std_devs, _ptr_of(scenes), n_scenes, robot_w,
                           robot_h, bins.ctypes.data_as(C.POINTER(C.c_float)), acc.ctypes.data_as(C.POINTER(C.c_float)),
-                          len(bins), max_samples, seed, scene_id_base, _ptr_of(hits), _ptr_of(n_used), _ptr_of(rows),
+                          len(bins), max_samples, seed, scene_id_base, schedule[0], schedule[1], schedule[2],
+                          _ptr_of(hits), _ptr_of(n_used), _ptr_of(rows),
                           C.pointer(total), C.pointer(iters))
         self._check(self.lib.c2d_mc_scenes(self.h, C.byref(a), C.c_void_p(stream)), "c2d_mc_scenes")
         return int(total.value), int(iters.value)

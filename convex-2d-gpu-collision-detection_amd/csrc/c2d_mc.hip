@@ -417,7 +417,13 @@ int c2d_mc_scenes(c2d_ctx* ctx, const c2d_mc_scenes_args* a, c2d_stream stream)
     if (a->num_poses == 0 || a->num_std_devs == 0) return fail_arg(ctx, "c2d_mc_scenes: empty pose / std_dev table");
     if (a->n_accuracy_bins < 2 || a->n_accuracy_bins > 16) return fail_arg(ctx, "c2d_mc_scenes: n_accuracy_bins must be 2..16");
     if (a->n_scenes > 0xffffffffull) return fail_arg(ctx, "c2d_mc_scenes: more than 2^32-1 scenes in one call");
-    if (a->max_samples == 0 || a->max_samples > 0x7fffffffu - C2D_MC_LARGE_BATCH)
+    uint32_t small_batch = C2D_MC_SMALL_BATCH, large_batch = C2D_MC_LARGE_BATCH, switch_at = C2D_MC_SWITCH_AT;
+    if (a->schedule_small_batch || a->schedule_large_batch || a->schedule_switch_at) {
+        small_batch = a->schedule_small_batch; large_batch = a->schedule_large_batch; switch_at = a->schedule_switch_at;
+        if (small_batch == 0 || large_batch == 0 || small_batch > (1u << 24) || large_batch > (1u << 24))
+            return fail_arg(ctx, "c2d_mc_scenes: schedule batches must be 1..2^24");
+    }
+    if (a->max_samples == 0 || a->max_samples > 0x7fffffffu - large_batch - small_batch)
         return fail_arg(ctx, "c2d_mc_scenes: max_samples out of range");
     DeviceGuard g(ctx->device);
     hipStream_t s = (hipStream_t)stream;
@@ -438,7 +444,7 @@ int c2d_mc_scenes(c2d_ctx* ctx, const c2d_mc_scenes_args* a, c2d_stream stream)
     const uint32_t* cur = nullptr;  // identity on the first step
     int flip = 0;
     while (n_active > 0 && n_samples < a->max_samples) {  // ccp.cu:281
-        const uint32_t n_batch = n_samples < C2D_MC_SWITCH_AT ? C2D_MC_SMALL_BATCH : C2D_MC_LARGE_BATCH;  // ccp.cu:283-286
+        const uint32_t n_batch = n_samples < switch_at ? small_batch : large_batch;  // ccp.cu:283-286
         ScenesArgs A;
         A.poses = a->d_poses; A.std_devs = a->d_std_devs; A.scenes = a->d_scenes;
         A.active = cur; A.n_active = n_active;

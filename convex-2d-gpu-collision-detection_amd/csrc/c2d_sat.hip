@@ -102,24 +102,52 @@ __global__ __launch_bounds__(BLOCK) void sat_rect_verts_kernel(Planes16 P, size_
     if (d_count) wave_count_arrive(my_count, d_count, words);
 }
 
-// ---- rectangle pairs, pose format (10 planes) -----------------------------------
-__global__ __launch_bounds__(kBlock) void sat_rect_pose_kernel(Planes10 P, size_t n, uint8_t* __restrict__ out,
-                                                               unsigned long long* __restrict__ d_count, unsigned long long* __restrict__ words)
+// ---- rectangle pairs, pose format (10 planes, 41 B/pair) ------------------------------
+// Same lane mapping as the vertex kernel (VEC == 4: one float4 per plane, 4 pairs
+// per lane); both rectangles are rebuilt per pair (2 sincos + 2 x 16 ops), which
+// moves this format towards the VALU roof: ~400 VALU instructions per 41 bytes.
+C2D_DEV uint32_t pose_pair_collides(const float (&v)[10])
+{
+    float r1[8], r2[8], s, c;
+    sincos_(v[4], s, c);
+    rect_from_half_extents(v[2] / 2, v[3] / 2, c, s, v[0], v[1], r1);
+    sincos_(v[9], s, c);
+    rect_from_half_extents(v[7] / 2, v[8] / 2, c, s, v[5], v[6], r2);
+    return rect_collide(r1, r2) ? 1u : 0u;
+}
+
+template <int VEC, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void sat_rect_pose_kernel(Planes10 P, size_t first, size_t n_groups,
+                                                              uint8_t* __restrict__ out,
+                                                              unsigned long long* __restrict__ d_count,
+                                                              unsigned long long* __restrict__ words)
 {
     uint32_t my_count = 0;
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        float v[10];
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    for (size_t g = (size_t)blockIdx.x * BLOCK + threadIdx.x; g < n_groups; g += stride) {
+        if constexpr (VEC == 4) {
+            f32x4 q[10];
 #pragma unroll
-        for (int k = 0; k < 10; k++) v[k] = P.p[k][i];
-        float r1[8], r2[8], s, c;
-        sincos_(v[4], s, c);
-        rect_from_half_extents(v[2] / 2, v[3] / 2, c, s, v[0], v[1], r1);
-        sincos_(v[9], s, c);
-        rect_from_half_extents(v[7] / 2, v[8] / 2, c, s, v[5], v[6], r2);
-        uint32_t hit = rect_collide(r1, r2) ? 1u : 0u;
-        out[i] = (uint8_t)hit;
-        my_count += hit;
+            for (int k = 0; k < 10; k++) q[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P.p[k]) + g);
+            uint32_t packed = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float v[10];
+#pragma unroll
+                for (int k = 0; k < 10; k++) v[k] = q[k][e];
+                packed |= pose_pair_collides(v) << (8 * e);
+            }
+            my_count += (uint32_t)__popc(packed);
+            __builtin_nontemporal_store(packed, reinterpret_cast<uint32_t*>(out) + g);
+        } else {
+            const size_t i = first + g;
+            float v[10];
+#pragma unroll
+            for (int k = 0; k < 10; k++) v[k] = P.p[k][i];
+            const uint32_t hit = pose_pair_collides(v);
+            out[i] = (uint8_t)hit;
+            my_count += hit;
+        }
     }
     if (d_count) wave_count_arrive(my_count, d_count, words);
 }
@@ -322,15 +350,28 @@ int c2d_sat_rect_pairs_pose(c2d_ctx* ctx, const float* const d_pose_planes[10], 
     if (n == 0) return C2D_OK;
     if (!d_pose_planes || !d_out) return fail_arg(ctx, "c2d_sat_rect_pairs_pose: NULL argument");
     Planes10 P;
+    bool wide = aligned_to(d_out, 4);
     for (int k = 0; k < 10; k++) {
         if (!d_pose_planes[k]) return fail_arg(ctx, "c2d_sat_rect_pairs_pose: NULL plane");
         P.p[k] = d_pose_planes[k];
+        wide = wide && aligned_to(d_pose_planes[k], 16);
     }
     DeviceGuard g(ctx->device);
-    const int grid = grid_for(n, kBlock, kMaxBlocks);
-    hipLaunchKernelGGL(sat_rect_pose_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, P, n, d_out, d_count,
-                       ctx->d_count_words);
-    C2D_LAUNCH_CHECK(ctx);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n4 = wide ? n / 4 : 0;
+    if (n4) {
+        const int grid = grid_for(n4, kWideBlock, kMaxBlocks);
+        hipLaunchKernelGGL((sat_rect_pose_kernel<4, kWideBlock>), dim3(grid), dim3(kWideBlock), 0, s, P, (size_t)0, n4, d_out,
+                           d_count, ctx->d_count_words);
+        C2D_LAUNCH_CHECK(ctx);
+    }
+    const size_t rest = n - 4 * n4;
+    if (rest) {
+        const int grid = grid_for(rest, kBlock, kMaxBlocks);
+        hipLaunchKernelGGL((sat_rect_pose_kernel<1, kBlock>), dim3(grid), dim3(kBlock), 0, s, P, 4 * n4, rest, d_out, d_count,
+                           ctx->d_count_words);
+        C2D_LAUNCH_CHECK(ctx);
+    }
     return C2D_OK;
 }
 

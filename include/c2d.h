@@ -214,6 +214,11 @@ typedef struct c2d_mc_scenes_args {
     uint32_t max_samples;         /* ccp.cu:38 default 4000000                         */
     uint64_t seed;
     uint64_t scene_id_base;
+    /* Sampling schedule; all three 0 = the reference default (C2D_MC_* above).  ztest.cu
+     * uses a constant batch of 10000 (ztest.cu:332-339): small = large = 10000. */
+    uint32_t schedule_small_batch;  /* batch size while n_samples < schedule_switch_at   */
+    uint32_t schedule_large_batch;  /* batch size afterwards                             */
+    uint32_t schedule_switch_at;
     uint32_t* d_hits;             /* device u32[n_scenes]  out: colliding samples      */
     uint32_t* d_n_used;           /* device u32[n_scenes]  out: samples drawn          */
     PoseCPVarAndPoseIdx* d_rows;  /* optional device rows (x,y,cp,var_idx,pose_idx) =

@@ -477,9 +477,13 @@ unsigned long long c2d_oracle_mc_scenes(const Pose* poses, uint32_t num_poses, c
                                         float robot_w, float robot_h, const float* accuracy_bins,
                                         const float* bin_accuracy, uint32_t n_accuracy_bins,
                                         uint32_t max_samples, uint64_t seed, uint64_t scene_id_base,
+                                        uint32_t small_batch, uint32_t large_batch, uint32_t switch_at,
                                         uint32_t* hits_out, uint32_t* n_used_out,
                                         PoseCPVarAndPoseIdx* rows)
 {
+    if (!small_batch && !large_batch && !switch_at) { /* reference default schedule */
+        small_batch = C2D_MC_SMALL_BATCH; large_batch = C2D_MC_LARGE_BATCH; switch_at = C2D_MC_SWITCH_AT;
+    }
     unsigned long long total = 0;
     (void)num_poses;
     (void)num_std_devs;
@@ -495,7 +499,7 @@ unsigned long long c2d_oracle_mc_scenes(const Pose* poses, uint32_t num_poses, c
         uint64_t sid = scene_id_base + (uint64_t)g;
         uint32_t n = 0, k = 0;
         while (n < max_samples) { /* ccp.cu:281 (num_left > 0 is this scene not being done) */
-            uint32_t nb = n < C2D_MC_SWITCH_AT ? C2D_MC_SMALL_BATCH : C2D_MC_LARGE_BATCH;
+            uint32_t nb = n < switch_at ? small_batch : large_batch; /* ccp.cu:283-286; ztest.cu:332 constant */
             for (uint32_t i = 0; i < nb; i++) k += (uint32_t)scene_sample(robot, obstacle, &sd, seed, sid, (uint64_t)n + i);
             n += nb;
             float slack = c2d_oracle_calc_slack(n, k);               /* ccp.cu:140 */

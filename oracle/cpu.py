@@ -225,7 +225,7 @@ def mc_sampled_rect(pose, sd, seed, scene_id, sample):
     return out
 
 
-def mc_scenes(poses, std_devs, scenes, robot_w, robot_h, bins, acc, max_samples, seed, scene_id_base=0):
+def mc_scenes(poses, std_devs, scenes, robot_w, robot_h, bins, acc, max_samples, seed, scene_id_base=0, schedule=(0, 0, 0)):
     """poses: POSE_DT[np]; std_devs: STD_DT[nv]; scenes: SCENE_DT[n].
     -> hits u32[n], n_used u32[n], rows ROW_DT[n], total samples"""
     poses = np.ascontiguousarray(poses, dtype=POSE_DT)
@@ -241,7 +241,8 @@ def mc_scenes(poses, std_devs, scenes, robot_w, robot_h, bins, acc, max_samples,
         C.c_void_p(poses.ctypes.data), C.c_uint32(len(poses)), C.c_void_p(std_devs.ctypes.data),
         C.c_uint32(len(std_devs)), C.c_void_p(scenes.ctypes.data), C.c_size_t(n), C.c_float(robot_w),
         C.c_float(robot_h), _ptr(bins), _ptr(acc), C.c_uint32(len(bins)), C.c_uint32(max_samples),
-        C.c_uint64(seed), C.c_uint64(scene_id_base), _ptr(hits, C.c_uint32), _ptr(used, C.c_uint32),
+        C.c_uint64(seed), C.c_uint64(scene_id_base), C.c_uint32(schedule[0]), C.c_uint32(schedule[1]), C.c_uint32(schedule[2]),
+        _ptr(hits, C.c_uint32), _ptr(used, C.c_uint32),
         C.c_void_p(rows.ctypes.data))
     return hits, used, rows, int(total)
 
