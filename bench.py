@@ -78,6 +78,10 @@ def main() -> None:
     ap.add_argument("--prewarm-ms", type=float, default=150.0,
                     help="untimed device wake-up before the W warm-up steps: the first ~15 ms of load after idle run "
                          "up to 12 %% slower while the power manager ramps clocks (profiles/r01a trace)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; nccl (= RCCL over xGMI) is the measured path, gloo only rehearses the N > 1 code "
+                         "path on a box with fewer GPUs than ranks (together with --share-device)")
+    ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mc", action="store_true")
     ap.add_argument("--no-pose", action="store_true")
@@ -107,11 +111,29 @@ def main() -> None:
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+
+    def all_reduce_sum(t):
+        """The one collective of each leg: sum of 64-bit counters over ranks, in place."""
+        if world == 1:
+            return
+        if args.backend == "nccl":
+            with torch.cuda.stream(stream):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        else:  # rehearsal backend: reduce a host copy
+            torch.cuda.synchronize()
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t.copy_(h)
 
     eng = pkg.Engine(local_rank)  # raises if libc2d.so is missing or the device is not gfx950
     stream = torch.cuda.Stream(device=dev)
@@ -167,9 +189,7 @@ def main() -> None:
         step()
     ev1.record(stream)
     total_count = count
-    if world > 1:
-        with torch.cuda.stream(stream):
-            dist.all_reduce(count, op=dist.ReduceOp.SUM)  # the single RCCL reduce of the hit counts
+    all_reduce_sum(count)  # the single RCCL reduce of the hit counts
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
@@ -240,9 +260,7 @@ def main() -> None:
         for _ in range(args.mc_reps):
             mc_step()
         e1.record(stream)
-        if world > 1:
-            with torch.cuda.stream(stream):
-                dist.all_reduce(hits, op=dist.ReduceOp.SUM)
+        all_reduce_sum(hits)
         torch.cuda.synchronize()
         barrier()
         m1 = time.perf_counter()
@@ -278,8 +296,7 @@ def main() -> None:
         hsum = torch.zeros(2, dtype=torch.int64, device=dev)
         hsum[0] = int(d_h.get().astype(np.int64).sum())
         hsum[1] = total
-        if world > 1:
-            dist.all_reduce(hsum, op=dist.ReduceOp.SUM)  # hit and sample totals: the one collective
+        all_reduce_sum(hsum)  # hit and sample totals: the one collective
         torch.cuda.synchronize()
         barrier()
         sel = shd.max_over_ranks(time.perf_counter() - s0, dev)
@@ -313,9 +330,7 @@ def main() -> None:
         preps = 10
         for _ in range(preps):
             poly_step()
-        if world > 1:
-            with torch.cuda.stream(stream):
-                dist.all_reduce(pcnt, op=dist.ReduceOp.SUM)
+        all_reduce_sum(pcnt)
         torch.cuda.synchronize()
         barrier()
         pel = shd.max_over_ranks(time.perf_counter() - p0, dev)

@@ -143,6 +143,7 @@ int main(int argc, char* argv[])
         stats.samples += total;
         stats.scenes += N;
         for (uint32_t h : hits) stats.hits += h;
+        for (const auto& r : dataset) stats.add_cp(r.cp);
         if (a.shuffle) std::shuffle(dataset.begin(), dataset.end(), std::default_random_engine(0));  // :346-349
         try {
             npy::save_f32(a.data_out + "/" + std::to_string(start_batch_count + batch_index) + ".npy", {N, 5},

@@ -91,6 +91,17 @@ inline std::vector<StdDev> std_devs_from_variances(const std::vector<float>& var
 }
 
 struct RunStats {
+    // histogram of cp over the bins of the reference's dataset tooling (balance_datasets.py:15-20, :36:
+    // [0,.001) [.001,.01) [.01,.1) [.1,1]) — what its plt.hist(data[:,2], accuracy_bins) draws
+    unsigned long long cp_hist[4] = {0, 0, 0, 0};
+    void add_cp(float cp)
+    {
+        static const float edges[5] = {0.0f, 0.001f, 0.01f, 0.1f, 1.0f};
+        for (int i = 0; i < 4; i++) {
+            const bool last = i == 3;
+            if (cp >= edges[i] && (last ? cp <= edges[i + 1] : cp < edges[i + 1])) { cp_hist[i]++; return; }
+        }
+    }
     unsigned long long samples = 0;
     unsigned long long hits = 0;
     unsigned long long scenes = 0;
@@ -100,6 +111,7 @@ struct RunStats {
 inline void print_json_summary(const char* tool, const Shard& sh, const RunStats& st, int batches)
 {
     std::printf("{\"tool\": \"%s\", \"rank\": %d, \"world_size\": %d, \"batches\": %d, \"scenes\": %llu, \"mc_samples\": %llu, "
-                "\"seconds\": %.3f, \"mc_samples_per_s\": %.4g}\n",
-                tool, sh.rank, sh.world, batches, st.scenes, st.samples, st.seconds, st.seconds > 0 ? st.samples / st.seconds : 0.0);
+                "\"seconds\": %.3f, \"mc_samples_per_s\": %.4g, \"cp_hist_bins\": [0, 0.001, 0.01, 0.1, 1], \"cp_hist\": [%llu, %llu, %llu, %llu]}\n",
+                tool, sh.rank, sh.world, batches, st.scenes, st.samples, st.seconds, st.seconds > 0 ? st.samples / st.seconds : 0.0,
+                st.cp_hist[0], st.cp_hist[1], st.cp_hist[2], st.cp_hist[3]);
 }

@@ -217,6 +217,7 @@ int main(int argc, char* argv[])
         stats.samples += total;
         stats.scenes += B;
         for (uint32_t h : hits) stats.hits += h;
+        for (const auto& r : dataset) stats.add_cp(r.cp);
         std::shuffle(dataset.begin(), dataset.end(), std::default_random_engine(0));  // :496
         try {
             npy::save_f32(data_dir + "/" + std::to_string(a.start_batch_count + batch_index) + ".npy", {B, 5},

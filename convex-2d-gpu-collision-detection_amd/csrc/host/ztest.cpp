@@ -125,6 +125,8 @@ int main(int argc, char* argv[])
     std::vector<PoseCPVarAndPoseIdx> dataset(N);
     C2D_CALL(ctx, c2d_memcpy_d2h(ctx, dataset.data(), d_rows, N * sizeof(PoseCPVarAndPoseIdx), stream));
     C2D_CALL(ctx, c2d_stream_synchronize(ctx, stream));
+    RunStats stats;
+    for (const auto& r : dataset) stats.add_cp(r.cp);
     try {
         if (cps_only) {  // ztest.cu:390-396, :416-418
             std::vector<float> cps(N);
@@ -140,7 +142,6 @@ int main(int argc, char* argv[])
         return EXIT_FAILURE;
     }
     const auto end = std::chrono::steady_clock::now();
-    RunStats stats;
     stats.samples = total; stats.scenes = N; stats.seconds = std::chrono::duration<double>(end - begin).count();
     std::cout << "Finished computation" << std::endl;
     std::cout << "Elapsed time: " << std::chrono::duration_cast<std::chrono::minutes>(end - begin).count() << " [min]" << std::endl;

@@ -26,6 +26,8 @@ def all_reduce_counters(values: Sequence[int], device=None):
     import torch
     import torch.distributed as dist
 
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "gloo":
+        device = None
     t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -39,6 +41,8 @@ def max_over_ranks(seconds: float, device=None) -> float:
 
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
         return float(seconds)
+    if dist.get_backend() == "gloo":
+        device = None  # rehearsal backend reduces on the host
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

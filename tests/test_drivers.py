@@ -104,6 +104,8 @@ def test_generate_dataset_end_to_end_matches_oracle(tmp_path, oracle):
         assert np.array_equal(key(rows), key(ref))
         assert not np.array_equal(rows, ref)                        # it was shuffled (generate_dataset.cu:496)
     assert summary["mc_samples"] == total and summary["scenes"] == B * NB
+    allrows = np.concatenate([np.load(d / f"{3 + b}.npy") for b in range(NB)])
+    assert summary["cp_hist"] == np.histogram(allrows[:, 2], [0, 0.001, 0.01, 0.1, 1])[0].tolist()   # balance_datasets.py:49
 
 
 @pytest.mark.gpu
