@@ -168,20 +168,28 @@ __global__ __launch_bounds__(kBlock) void rects_from_poses_kernel(const float* _
 }
 
 // ---- convex polygons, K <= 16, true normals ----------------------------------------
-// Work split: 32 lanes per pair, lane a owns axis a (edge a of polygon A for
-// a < ka, edge a-ka of polygon B otherwise), so all ka+kb axes of a pair are
-// evaluated side by side and "found a separating axis" is one ballot (the
-// wave-level equivalent of an early-out: no axis is ever evaluated after the
-// decision is known, because they all run at once).  Vertices are staged in LDS
-// by the whole block with coalesced loads (pair index fastest in memory), then
-// every lane walks the pair's vertex list two vertices per ds_read_b128; all
-// lanes of a half-wave read the same address (LDS broadcast).  The vertex lists
-// are padded to an even length by repeating the last vertex, which cannot
-// change a min or a max.  A block handles kPolyPairs pairs per pass.
+// Work split: kPolyLanes (= 32 / kPolyAxes) lanes per pair, a lane owns
+// kPolyAxes of the pair's ka+kb axes (axis l, l + kPolyLanes, ...), so all axes
+// of a pair are evaluated side by side and "found a separating axis" is one
+// ballot (the wave-level form of an early-out: nothing is evaluated after the
+// decision is known because every axis runs at once).  Vertices are staged in
+// LDS by the whole block with coalesced loads (pair index fastest in memory);
+// every lane then walks the pair's vertex list two vertices per ds_read_b128
+// (an LDS broadcast within the pair's lanes) and applies each vertex to all of
+// its axes from registers.  That register blocking is what matters: with one
+// axis per lane the kernel was bound by LDS instruction issue (one b128 read
+// per 10 VALU instructions on every SIMD), with four axes per lane it is one
+// read per 40.  Vertex lists are padded to an even length by repeating the
+// last vertex, which cannot change a min or a max.
 constexpr int kPolyPairs = 64;                  // pairs staged per block pass
-constexpr int kPolyStride = 2 * C2D_POLY_KMAX;  // vertices per pair slot (A then B)
+constexpr int kPolyStride = 2 * C2D_POLY_KMAX;  // vertices per pair slot (A then B) = max axes per pair
 constexpr int kPolyPitch = kPolyStride + 2;     // float2 per pair slot: 272 B = 17 x 16 B keeps b128 reads
-                                                // aligned and puts the two half-waves' rows on different banks
+                                                // aligned and puts neighbouring pairs on disjoint banks
+#ifndef C2D_POLY_AXES_PER_LANE
+#define C2D_POLY_AXES_PER_LANE 4
+#endif
+constexpr int kPolyAxes = C2D_POLY_AXES_PER_LANE;
+constexpr int kPolyLanes = kPolyStride / kPolyAxes;  // lanes per pair
 
 C2D_DEV void minmax_update(float nx, float ny, float x, float y, float& mn, float& mx)
 {
@@ -200,8 +208,8 @@ __global__ __launch_bounds__(kBlock) void sat_poly_kernel(const float* __restric
     __shared__ uint8_t s_k[2][kPolyPairs];
     uint32_t my_count = 0;
     const int tid = threadIdx.x;
-    const int half = tid >> 5;   // 0..7: which pair of the current group of 8
-    const int a = tid & 31;      // axis owned by this lane
+    const int group = tid / kPolyLanes;  // which pair of the current group of kBlock / kPolyLanes
+    const int l = tid % kPolyLanes;      // lane within the pair
     const size_t n_pass = (n + kPolyPairs - 1) / kPolyPairs;
     for (size_t pass = blockIdx.x; pass < n_pass; pass += gridDim.x) {
         const size_t base = pass * kPolyPairs;
@@ -226,41 +234,56 @@ __global__ __launch_bounds__(kBlock) void sat_poly_kernel(const float* __restric
             }
         }
         __syncthreads();
-        // evaluate: 8 pairs at a time (one per half-wave)
-        for (int j0 = 0; j0 < pairs_here; j0 += kBlock / 32) {
-            const int j = j0 + half;
+        // evaluate: kBlock / kPolyLanes pairs at a time
+        for (int j0 = 0; j0 < pairs_here; j0 += kBlock / kPolyLanes) {
+            const int j = j0 + group;
             const bool live = j < pairs_here;
-            const int ka = live ? (int)s_k[0][j] : 0, kb = live ? (int)s_k[1][j] : 0;
-            bool sep = false;
-            if (a < ka + kb) {
-                const float2* A = &s_v[j][0];
-                const float2* B = &s_v[j][C2D_POLY_KMAX];
+            const int jj = live ? j : 0;
+            const int ka = live ? (int)s_k[0][jj] : 0, kb = live ? (int)s_k[1][jj] : 0;
+            const float2* A = &s_v[jj][0];
+            const float2* B = &s_v[jj][C2D_POLY_KMAX];
+            float nx[kPolyAxes], ny[kPolyAxes], min1[kPolyAxes], max1[kPolyAxes], min2[kPolyAxes], max2[kPolyAxes];
+            bool valid[kPolyAxes];
+#pragma unroll
+            for (int r = 0; r < kPolyAxes; r++) {
+                const int a = l + r * kPolyLanes;
+                valid[r] = a < ka + kb;
                 const bool onA = a < ka;
                 const float2* Pn = onA ? A : B;
                 const int kp = onA ? ka : kb;
-                const int i = onA ? a : a - ka;
-                const int i1 = (i + 1 == kp) ? 0 : i + 1;
+                const int i = valid[r] ? (onA ? a : a - ka) : 0;
+                const int i1 = (i + 1 >= kp) ? 0 : i + 1;
                 const float2 e0 = Pn[i], e1 = Pn[i1];
-                const float ex = e1.x - e0.x, ey = e1.y - e0.y;
-                const float nx = -ey, ny = ex;
-                float min1 = __builtin_inff(), max1 = -__builtin_inff(), min2 = __builtin_inff(), max2 = -__builtin_inff();
-                const float4* A4 = reinterpret_cast<const float4*>(A);
-                const float4* B4 = reinterpret_cast<const float4*>(B);
-                for (int k = 0; 2 * k < ka; k++) {
-                    const float4 q = A4[k];
-                    minmax_update(nx, ny, q.x, q.y, min1, max1);
-                    minmax_update(nx, ny, q.z, q.w, min1, max1);
-                }
-                for (int k = 0; 2 * k < kb; k++) {
-                    const float4 q = B4[k];
-                    minmax_update(nx, ny, q.x, q.y, min2, max2);
-                    minmax_update(nx, ny, q.z, q.w, min2, max2);
-                }
-                sep = (max1 < min2) || (max2 < min1);
+                nx[r] = -(e1.y - e0.y);   // true normal (-ey, ex)
+                ny[r] = e1.x - e0.x;
+                min1[r] = min2[r] = __builtin_inff();
+                max1[r] = max2[r] = -__builtin_inff();
             }
+            const float4* A4 = reinterpret_cast<const float4*>(A);
+            const float4* B4 = reinterpret_cast<const float4*>(B);
+            for (int k = 0; 2 * k < ka; k++) {
+                const float4 q = A4[k];
+#pragma unroll
+                for (int r = 0; r < kPolyAxes; r++) {
+                    minmax_update(nx[r], ny[r], q.x, q.y, min1[r], max1[r]);
+                    minmax_update(nx[r], ny[r], q.z, q.w, min1[r], max1[r]);
+                }
+            }
+            for (int k = 0; 2 * k < kb; k++) {
+                const float4 q = B4[k];
+#pragma unroll
+                for (int r = 0; r < kPolyAxes; r++) {
+                    minmax_update(nx[r], ny[r], q.x, q.y, min2[r], max2[r]);
+                    minmax_update(nx[r], ny[r], q.z, q.w, min2[r], max2[r]);
+                }
+            }
+            bool sep = false;
+#pragma unroll
+            for (int r = 0; r < kPolyAxes; r++) sep |= valid[r] && ((max1[r] < min2[r]) || (max2[r] < min1[r]));
             const unsigned long long ballot = __ballot(sep);
-            const uint32_t mine = (uint32_t)(ballot >> (32 * (half & 1)));
-            if (a == 0 && live) {
+            const int shift = (tid & 63) - l;  // first lane of this pair within the wave
+            const unsigned long long mine = (ballot >> shift) & ((1ull << kPolyLanes) - 1ull);
+            if (l == 0 && live) {
                 const uint32_t c = mine == 0 ? 1u : 0u;
                 out[base + j] = (uint8_t)c;
                 my_count += c;
