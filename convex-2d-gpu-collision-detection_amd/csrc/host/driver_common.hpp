@@ -96,10 +96,12 @@ struct RunStats {
     unsigned long long cp_hist[4] = {0, 0, 0, 0};
     void add_cp(float cp)
     {
-        static const float edges[5] = {0.0f, 0.001f, 0.01f, 0.1f, 1.0f};
+        // double edges against the promoted float32 value, as numpy / matplotlib compare them
+        static const double edges[5] = {0.0, 0.001, 0.01, 0.1, 1.0};
+        const double v = cp;
         for (int i = 0; i < 4; i++) {
             const bool last = i == 3;
-            if (cp >= edges[i] && (last ? cp <= edges[i + 1] : cp < edges[i + 1])) { cp_hist[i]++; return; }
+            if (v >= edges[i] && (last ? v <= edges[i + 1] : v < edges[i + 1])) { cp_hist[i]++; return; }
         }
     }
     unsigned long long samples = 0;
