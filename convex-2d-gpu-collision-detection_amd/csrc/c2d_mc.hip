@@ -135,34 +135,72 @@ __global__ __launch_bounds__(kMcBlock) void mc_pair_kernel(PairArgs A, unsigned 
 }
 
 // ---- many scenes, adaptive (BASELINE config 4) --------------------------------------
+// The schedule state lives on the device, so the host enqueues the whole adaptive
+// loop (advance, decide, advance, decide, ...) without a single read-back: the
+// number of unfinished scenes, the samples drawn so far and the work split of the
+// next step are read by the kernels themselves.  Steps enqueued after every scene
+// has finished see n_active == 0 and retire at once.
+struct AdaptiveState {
+    uint32_t n_active;     // scenes still sampling
+    uint32_t next_count;   // survivors appended by the running decide step
+    uint32_t n_samples;    // samples drawn so far for every active scene
+    uint32_t iter;         // schedule steps executed
+    uint32_t ticket;       // blocks of the decide step that have finished
+    uint32_t list_sel;     // which list holds the active indices
+    uint32_t identity;     // 1: the active list is 0..n_active-1 (first step)
+    uint32_t pad;
+    unsigned long long total_samples;
+};
+
+struct ScheduleArgs {
+    uint32_t small_batch, large_batch, switch_at, max_samples;
+    uint32_t want_waves;   // waves that fill the chip (CUs x 32)
+};
+
+C2D_DEV uint32_t batch_of(const ScheduleArgs& S, uint32_t n_samples)
+{
+    return n_samples < S.switch_at ? S.small_batch : S.large_batch;  // ccp.cu:283-286
+}
+
 struct ScenesArgs {
     const Pose* poses;
     const StdDev* std_devs;
     const PositionWithVarAndPoseIdx* scenes;
-    const uint32_t* active;   // indices of unfinished scenes, or NULL = identity
-    uint32_t n_active;
+    AdaptiveState* state;
+    uint32_t* lists[2];       // active-scene index lists (ping-pong)
     uint32_t num_poses, num_std_devs;
     float robot_w, robot_h;
     uint64_t seed, scene_id_base;
-    uint32_t n_start;         // samples already drawn for every active scene
-    uint32_t n_batch;         // samples to draw now
-    uint32_t waves_per_scene; // sample chunks per scene
-    uint32_t chunk;           // samples per chunk (multiple of 64)
+    ScheduleArgs sched;
     uint32_t* hits;           // u32[n_scenes], accumulated
 };
 
 __global__ __launch_bounds__(kMcBlock) void mc_scenes_advance_kernel(ScenesArgs A)
 {
+    const uint32_t n_active = A.state->n_active;
+    if (n_active == 0) return;
+    const uint32_t n_start = A.state->n_samples;
+    if (n_start >= A.sched.max_samples) return;  // ccp.cu:281
+    const uint32_t n_batch = batch_of(A.sched, n_start);
+    const uint32_t* active = A.state->identity ? nullptr : A.lists[A.state->list_sel];
+    // split a scene's batch over several waves when few scenes are left, so that the
+    // tail of the adaptive loop still fills the chip
+    const uint32_t max_split = (n_batch + 63) / 64;
+    uint32_t wps = (A.sched.want_waves + n_active - 1) / n_active;
+    wps = wps < 1 ? 1 : (wps > max_split ? max_split : wps);
+    uint32_t chunk = (n_batch + wps - 1) / wps;
+    chunk = ((chunk + 63) / 64) * 64;
+    wps = (n_batch + chunk - 1) / chunk;
+
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t n_items = (uint64_t)A.n_active * A.waves_per_scene;
+    const uint64_t n_items = (uint64_t)n_active * wps;
     for (uint64_t item = (uint64_t)blockIdx.x * kWavesPerBlock + wave; item < n_items;
          item += (uint64_t)gridDim.x * kWavesPerBlock) {
-        const uint32_t slot = (uint32_t)(item / A.waves_per_scene);
-        const uint32_t ch = (uint32_t)(item % A.waves_per_scene);
-        const uint32_t off = ch * A.chunk;
-        if (off >= A.n_batch) continue;
-        const uint32_t count = (A.n_batch - off) < A.chunk ? (A.n_batch - off) : A.chunk;
-        const uint32_t g = A.active ? A.active[slot] : slot;
+        const uint32_t slot = (uint32_t)(item / wps);
+        const uint32_t ch = (uint32_t)(item % wps);
+        const uint32_t off = ch * chunk;
+        const uint32_t count = (n_batch - off) < chunk ? (n_batch - off) : chunk;
+        const uint32_t g = active ? active[slot] : slot;
         const PositionWithVarAndPoseIdx row = A.scenes[g];
         // float -> int index conversion as in ccp.cu:121-122; clamped so that a
         // malformed row cannot read outside the tables
@@ -172,7 +210,7 @@ __global__ __launch_bounds__(kMcBlock) void mc_scenes_advance_kernel(ScenesArgs 
         const Pose pose = A.poses[pi];
         const StdDev sd = A.std_devs[vi];
         const Scene sc = make_scene(A.robot_w, A.robot_h, row.x, row.y, pose, sd);
-        const uint32_t h = wave_count_hits(sc, A.seed, A.scene_id_base + g, (uint64_t)A.n_start + off, count);
+        const uint32_t h = wave_count_hits(sc, A.seed, A.scene_id_base + g, (uint64_t)n_start + off, count);
         if ((threadIdx.x & 63) == 0 && h) atomicAdd(&A.hits[g], h);
     }
 }
@@ -200,55 +238,89 @@ C2D_DEV int get_bin(float p, const float* bins, uint32_t n_bins)
 }
 
 // After a batch: stop test of ccp.cu:140-148 per active scene, compaction of the
-// survivors into `next` (replaces thrust::count + sort_by_key, ccp.cu:307-311),
-// and write_collision_probability (utils.cu:210-215) for the finished ones.
+// survivors into the other list (replaces thrust::count + sort_by_key,
+// ccp.cu:307-311), write_collision_probability (utils.cu:210-215) for the
+// finished ones, and — by the block that finishes last — the roll of the schedule
+// state for the next step.
 struct DecideArgs {
     const PositionWithVarAndPoseIdx* scenes;
-    const uint32_t* active;
-    uint32_t n_active;
-    uint32_t n_samples;     // total drawn so far for the active scenes
-    uint32_t max_samples;
-    const float* bins;      // device: accuracy_bins[n_bins] then bin_accuracy[n_bins-1]
+    AdaptiveState* state;
+    uint32_t* lists[2];
+    ScheduleArgs sched;
+    float bins[16];         // accuracy_bins
+    float acc[16];          // bin_accuracy
     uint32_t n_bins;
     const uint32_t* hits;
     uint32_t* n_used;
     PoseCPVarAndPoseIdx* rows;  // may be NULL
-    uint32_t* next;         // survivors
-    uint32_t* next_count;
 };
 
 __global__ __launch_bounds__(256) void mc_scenes_decide_kernel(DecideArgs A)
 {
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    bool survive = false;
-    uint32_t g = 0;
-    if (slot < A.n_active) {
-        g = A.active ? A.active[slot] : slot;
-        const uint32_t k = A.hits[g];
-        const uint32_t n = A.n_samples;
-        const float slack = calc_slack(n, k);
-        const float p = (float)k / (float)n;
-        const bool done = slack <= A.bins[A.n_bins + get_bin(p, A.bins, A.n_bins)];
-        if (done || n >= A.max_samples) {
-            A.n_used[g] = n;
-            if (A.rows) {
-                const PositionWithVarAndPoseIdx row = A.scenes[g];
-                PoseCPVarAndPoseIdx o;
-                o.x = row.x; o.y = row.y; o.cp = p; o.var_idx = row.var_idx; o.pose_idx = row.pose_idx;
-                A.rows[g] = o;
+    const uint32_t n_active = A.state->n_active;
+    if (n_active == 0) return;
+    const uint32_t n_start = A.state->n_samples;
+    if (n_start >= A.sched.max_samples) return;
+    const uint32_t n_batch = batch_of(A.sched, n_start);
+    const uint32_t n = n_start + n_batch;
+    const bool identity = A.state->identity != 0;
+    const uint32_t sel = A.state->list_sel;
+    const uint32_t* active = identity ? nullptr : A.lists[sel];
+    uint32_t* next = A.lists[identity ? 0 : (sel ^ 1u)];
+    __shared__ float s_bins[16], s_acc[16];
+    if (threadIdx.x < 16) { s_bins[threadIdx.x] = A.bins[threadIdx.x]; s_acc[threadIdx.x] = A.acc[threadIdx.x]; }
+    __syncthreads();
+
+    const uint32_t rounds = (n_active + gridDim.x * blockDim.x - 1) / (gridDim.x * blockDim.x);
+    for (uint32_t r = 0; r < rounds; r++) {  // every lane takes part in every round's ballot
+        const uint32_t slot = (r * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+        bool survive = false;
+        uint32_t g = 0;
+        if (slot < n_active) {
+            g = active ? active[slot] : slot;
+            const uint32_t k = A.hits[g];
+            const float slack = calc_slack(n, k);                         // ccp.cu:140
+            const float p = (float)k / (float)n;                          // ccp.cu:142
+            const bool done = slack <= s_acc[get_bin(p, s_bins, A.n_bins)];  // ccp.cu:144
+            if (done || n >= A.sched.max_samples) {
+                A.n_used[g] = n;
+                if (A.rows) {
+                    const PositionWithVarAndPoseIdx row = A.scenes[g];
+                    PoseCPVarAndPoseIdx o;
+                    o.x = row.x; o.y = row.y; o.cp = p; o.var_idx = row.var_idx; o.pose_idx = row.pose_idx;
+                    A.rows[g] = o;
+                }
+            } else {
+                survive = true;
             }
-        } else {
-            survive = true;
+        }
+        // wave-aggregated append: one atomic per wave
+        const unsigned long long m = __ballot(survive);
+        if (m) {
+            const uint32_t lane = threadIdx.x & 63;
+            uint32_t base = 0;
+            if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(&A.state->next_count, (uint32_t)__popcll(m));
+            base = __shfl(base, __builtin_ctzll(m), 64);
+            if (survive) next[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = g;
         }
     }
-    // wave-aggregated append: one atomic per wave
-    const unsigned long long m = __ballot(survive);
-    if (m) {
-        const uint32_t lane = threadIdx.x & 63;
-        uint32_t base = 0;
-        if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(A.next_count, (uint32_t)__popcll(m));
-        base = __shfl(base, __builtin_ctzll(m), 64);
-        if (survive) A.next[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = g;
+    // The block whose ticket is the last one rolls the state.  Every append above is a
+    // returning device-scope atomic that has completed, and the fence orders this block's
+    // list stores before its ticket; the next kernel starts behind the kernel boundary.
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const uint32_t t = atomicAdd(&A.state->ticket, 1u);
+        if (t == gridDim.x - 1) {
+            const uint32_t survivors = atomicExch(&A.state->next_count, 0u);
+            A.state->total_samples += (unsigned long long)n_active * n_batch;
+            A.state->n_active = survivors;
+            A.state->n_samples = n;
+            A.state->iter += 1;
+            A.state->ticket = 0;
+            A.state->list_sel = identity ? 0u : (sel ^ 1u);
+            A.state->identity = 0;
+        }
     }
 }
 
@@ -417,80 +489,72 @@ int c2d_mc_scenes(c2d_ctx* ctx, const c2d_mc_scenes_args* a, c2d_stream stream)
     if (a->num_poses == 0 || a->num_std_devs == 0) return fail_arg(ctx, "c2d_mc_scenes: empty pose / std_dev table");
     if (a->n_accuracy_bins < 2 || a->n_accuracy_bins > 16) return fail_arg(ctx, "c2d_mc_scenes: n_accuracy_bins must be 2..16");
     if (a->n_scenes > 0xffffffffull) return fail_arg(ctx, "c2d_mc_scenes: more than 2^32-1 scenes in one call");
-    uint32_t small_batch = C2D_MC_SMALL_BATCH, large_batch = C2D_MC_LARGE_BATCH, switch_at = C2D_MC_SWITCH_AT;
+    ScheduleArgs S;
+    S.small_batch = C2D_MC_SMALL_BATCH; S.large_batch = C2D_MC_LARGE_BATCH; S.switch_at = C2D_MC_SWITCH_AT;
     if (a->schedule_small_batch || a->schedule_large_batch || a->schedule_switch_at) {
-        small_batch = a->schedule_small_batch; large_batch = a->schedule_large_batch; switch_at = a->schedule_switch_at;
-        if (small_batch == 0 || large_batch == 0 || small_batch > (1u << 24) || large_batch > (1u << 24))
+        S.small_batch = a->schedule_small_batch; S.large_batch = a->schedule_large_batch; S.switch_at = a->schedule_switch_at;
+        if (S.small_batch == 0 || S.large_batch == 0 || S.small_batch > (1u << 24) || S.large_batch > (1u << 24))
             return fail_arg(ctx, "c2d_mc_scenes: schedule batches must be 1..2^24");
     }
-    if (a->max_samples == 0 || a->max_samples > 0x7fffffffu - large_batch - small_batch)
+    if (a->max_samples == 0 || a->max_samples > 0x7fffffffu - S.large_batch - S.small_batch)
         return fail_arg(ctx, "c2d_mc_scenes: max_samples out of range");
+    S.max_samples = a->max_samples;
+    const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
+    S.want_waves = cus * 32;
+    // number of schedule steps until n_samples >= max_samples (ccp.cu:281-287)
+    uint32_t steps = 0;
+    for (uint64_t ns = 0; ns < a->max_samples; steps++) ns += ns < S.switch_at ? S.small_batch : S.large_batch;
+    if (steps > 100000) return fail_arg(ctx, "c2d_mc_scenes: more than 100000 schedule steps; use larger batches");
+
     DeviceGuard g(ctx->device);
     hipStream_t s = (hipStream_t)stream;
     int st = ensure_lists(ctx, a->n_scenes);
     if (st != C2D_OK) return st;
+    AdaptiveState* d_state = reinterpret_cast<AdaptiveState*>(ctx->d_counters);
+    static_assert(sizeof(AdaptiveState) <= 64, "AdaptiveState must fit the ctx counter block");
 
-    float h_bins[32];
-    for (uint32_t i = 0; i < a->n_accuracy_bins; i++) h_bins[i] = a->accuracy_bins[i];
-    for (uint32_t i = 0; i + 1 < a->n_accuracy_bins; i++) h_bins[a->n_accuracy_bins + i] = a->bin_accuracy[i];
-    C2D_HIP(ctx, hipMemcpyAsync(ctx->d_bins, h_bins, (2 * a->n_accuracy_bins - 1) * sizeof(float), hipMemcpyHostToDevice, s));
-    C2D_HIP(ctx, hipStreamSynchronize(s));  // h_bins is a stack buffer
+    AdaptiveState init{};
+    init.n_active = (uint32_t)a->n_scenes;
+    init.identity = 1;
+    // a 40-byte H2D copy from pageable memory is staged by the runtime before the call returns
+    C2D_HIP(ctx, hipMemcpyAsync(d_state, &init, sizeof init, hipMemcpyHostToDevice, s));
     C2D_HIP(ctx, hipMemsetAsync(a->d_hits, 0, a->n_scenes * sizeof(uint32_t), s));
 
-    const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
-    uint32_t n_active = (uint32_t)a->n_scenes;
-    uint32_t n_samples = 0, iter = 0;
-    uint64_t total = 0;
-    const uint32_t* cur = nullptr;  // identity on the first step
-    int flip = 0;
-    while (n_active > 0 && n_samples < a->max_samples) {  // ccp.cu:281
-        const uint32_t n_batch = n_samples < switch_at ? small_batch : large_batch;  // ccp.cu:283-286
-        ScenesArgs A;
-        A.poses = a->d_poses; A.std_devs = a->d_std_devs; A.scenes = a->d_scenes;
-        A.active = cur; A.n_active = n_active;
-        A.num_poses = a->num_poses; A.num_std_devs = a->num_std_devs;
-        A.robot_w = a->robot_w; A.robot_h = a->robot_h;
-        A.seed = a->seed; A.scene_id_base = a->scene_id_base;
-        A.n_start = n_samples; A.n_batch = n_batch;
-        // split a scene's batch over several waves when few scenes are left, so
-        // that the tail of the adaptive loop still fills the chip
-        const uint32_t max_split = (n_batch + 63) / 64;
-        const uint64_t want_waves = (uint64_t)cus * 32;
-        uint32_t wps = (uint32_t)((want_waves + n_active - 1) / n_active);
-        if (wps < 1) wps = 1;
-        if (wps > max_split) wps = max_split;
-        uint32_t chunk = (n_batch + wps - 1) / wps;
-        chunk = ((chunk + 63) / 64) * 64;
-        wps = (n_batch + chunk - 1) / chunk;
-        A.waves_per_scene = wps; A.chunk = chunk;
-        A.hits = a->d_hits;
-        const uint64_t items = (uint64_t)n_active * wps;
-        uint64_t blocks = (items + kWavesPerBlock - 1) / kWavesPerBlock;
-        const uint64_t max_blocks = (uint64_t)cus * 64;
-        if (blocks > max_blocks) blocks = max_blocks;
-        hipLaunchKernelGGL(mc_scenes_advance_kernel, dim3((unsigned)blocks), dim3(kMcBlock), 0, s, A);
-        C2D_LAUNCH_CHECK(ctx);
-        n_samples += n_batch;
-        total += (uint64_t)n_active * n_batch;
-
-        C2D_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(uint32_t), s));
-        DecideArgs D;
-        D.scenes = a->d_scenes; D.active = cur; D.n_active = n_active;
-        D.n_samples = n_samples; D.max_samples = a->max_samples;
-        D.bins = ctx->d_bins; D.n_bins = a->n_accuracy_bins;
-        D.hits = a->d_hits; D.n_used = a->d_n_used; D.rows = a->d_rows;
-        D.next = ctx->d_list[flip]; D.next_count = ctx->d_counters;
-        hipLaunchKernelGGL(mc_scenes_decide_kernel, dim3((n_active + 255) / 256), dim3(256), 0, s, D);
-        C2D_LAUNCH_CHECK(ctx);
-        C2D_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, ctx->d_counters, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        C2D_HIP(ctx, hipStreamSynchronize(s));
-        n_active = ctx->h_pinned[0];
-        cur = ctx->d_list[flip];
-        flip ^= 1;
-        iter++;
+    ScenesArgs A;
+    A.poses = a->d_poses; A.std_devs = a->d_std_devs; A.scenes = a->d_scenes;
+    A.state = d_state; A.lists[0] = ctx->d_list[0]; A.lists[1] = ctx->d_list[1];
+    A.num_poses = a->num_poses; A.num_std_devs = a->num_std_devs;
+    A.robot_w = a->robot_w; A.robot_h = a->robot_h;
+    A.seed = a->seed; A.scene_id_base = a->scene_id_base;
+    A.sched = S; A.hits = a->d_hits;
+    DecideArgs D;
+    D.scenes = a->d_scenes; D.state = d_state; D.lists[0] = ctx->d_list[0]; D.lists[1] = ctx->d_list[1];
+    D.sched = S; D.n_bins = a->n_accuracy_bins;
+    for (uint32_t i = 0; i < 16; i++) {
+        D.bins[i] = i < a->n_accuracy_bins ? a->accuracy_bins[i] : 0.0f;
+        D.acc[i] = i + 1 < a->n_accuracy_bins ? a->bin_accuracy[i] : 0.0f;
     }
-    if (a->total_samples) *a->total_samples = total;
-    if (a->iterations) *a->iterations = iter;
+    D.hits = a->d_hits; D.n_used = a->d_n_used; D.rows = a->d_rows;
+
+    // grids sized for the largest step (every scene active); later steps leave blocks idle
+    uint64_t adv_blocks = (a->n_scenes * (uint64_t)1 + kWavesPerBlock - 1) / kWavesPerBlock;
+    const uint64_t adv_min = (uint64_t)cus * 8, adv_max = (uint64_t)cus * 64;
+    adv_blocks = adv_blocks < adv_min ? adv_min : (adv_blocks > adv_max ? adv_max : adv_blocks);
+    uint64_t dec_blocks = (a->n_scenes + 255) / 256;
+    const uint64_t dec_max = (uint64_t)cus * 4;
+    dec_blocks = dec_blocks > dec_max ? dec_max : dec_blocks;
+    for (uint32_t it = 0; it < steps; it++) {
+        hipLaunchKernelGGL(mc_scenes_advance_kernel, dim3((unsigned)adv_blocks), dim3(kMcBlock), 0, s, A);
+        hipLaunchKernelGGL(mc_scenes_decide_kernel, dim3((unsigned)dec_blocks), dim3(256), 0, s, D);
+    }
+    C2D_LAUNCH_CHECK(ctx);
+    if (a->total_samples || a->iterations) {  // host outputs requested: one read-back at the end
+        AdaptiveState* h_state = reinterpret_cast<AdaptiveState*>(ctx->h_pinned);
+        C2D_HIP(ctx, hipMemcpyAsync(h_state, d_state, sizeof(AdaptiveState), hipMemcpyDeviceToHost, s));
+        C2D_HIP(ctx, hipStreamSynchronize(s));
+        if (a->total_samples) *a->total_samples = h_state->total_samples;
+        if (a->iterations) *a->iterations = h_state->iter;
+    }
     return C2D_OK;
 }
 

@@ -198,7 +198,9 @@ int c2d_mc_pair(c2d_ctx* ctx, float robot_w, float robot_h, const Position* pos,
  * the first check that passes, or when n_samples >= max_samples.
  * Scene i uses random stream (seed, scene_id_base + i), so results do not
  * depend on batching, completion order or the number of GPUs.
- * This call synchronises `stream` (the schedule is driven from the host). */
+ * The whole loop is enqueued on `stream` without any read-back (the schedule
+ * state lives on the device); the call only synchronises when a host output
+ * (total_samples, iterations) is requested. */
 typedef struct c2d_mc_scenes_args {
     const Pose* d_poses;          /* device Pose[num_poses]          (utils.cu:91-94)  */
     uint32_t num_poses;
