@@ -175,6 +175,14 @@ struct ScenesArgs {
     uint32_t* hits;           // u32[n_scenes], accumulated
 };
 
+__global__ void mc_scenes_init_kernel(AdaptiveState* state, uint32_t n_scenes)
+{
+    AdaptiveState init{};
+    init.n_active = n_scenes;
+    init.identity = 1;
+    *state = init;
+}
+
 __global__ __launch_bounds__(kMcBlock) void mc_scenes_advance_kernel(ScenesArgs A)
 {
     const uint32_t n_active = A.state->n_active;
@@ -513,11 +521,7 @@ int c2d_mc_scenes(c2d_ctx* ctx, const c2d_mc_scenes_args* a, c2d_stream stream)
     AdaptiveState* d_state = reinterpret_cast<AdaptiveState*>(ctx->d_counters);
     static_assert(sizeof(AdaptiveState) <= 64, "AdaptiveState must fit the ctx counter block");
 
-    AdaptiveState init{};
-    init.n_active = (uint32_t)a->n_scenes;
-    init.identity = 1;
-    // a 40-byte H2D copy from pageable memory is staged by the runtime before the call returns
-    C2D_HIP(ctx, hipMemcpyAsync(d_state, &init, sizeof init, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(mc_scenes_init_kernel, dim3(1), dim3(1), 0, s, d_state, (uint32_t)a->n_scenes);
     C2D_HIP(ctx, hipMemsetAsync(a->d_hits, 0, a->n_scenes * sizeof(uint32_t), s));
 
     ScenesArgs A;

@@ -7,9 +7,9 @@ import socket
 
 import numpy as np
 import pytest
-import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
+
+# torch is imported inside the tests: the GPU run (-m gpu) collects this module too and should
+# not pay for (or be affected by) torch's bundled HIP runtime.
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -24,6 +24,8 @@ def _free_port():
 
 def _worker(rank, world, port, q):
     import sys
+
+    import torch.distributed as dist
 
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -82,6 +84,8 @@ def test_shard_range_partitions_exactly(pkg):
 
 
 def test_two_rank_gloo_sharding_reproduces_single_process(oracle, wl):
+    import torch.multiprocessing as mp
+
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
