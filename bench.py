@@ -209,7 +209,7 @@ def main() -> None:
                 traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "sat_rect_verts_kernel<4>", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS,
+    roofline = {"bound": "hbm", "kernel": "sat_rect_verts_kernel<4, 64>", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": BYTES_PER_PAIR * n, "kernel_ms": round(kernel_ms, 5)}
 

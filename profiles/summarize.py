@@ -50,7 +50,7 @@ def main():
         if len(sys.argv) >= 6:
             pairs = int(sys.argv[5])
             for k, v in res.items():
-                if "sat_rect_verts_kernel<4>" in k:
+                if "sat_rect_verts_kernel<4" in k:
                     json.dump({"pairs": pairs, "kernel": k, "hbm_bytes_per_launch": v["hbm_bytes_per_launch_corrected"],
                                "algorithmic_bytes_per_launch": 65 * pairs, "source": f"profiles/{tag}_pmc_hbm.json"},
                               open(os.path.join(here, "sat_rect_verts_traffic.json"), "w"), indent=1)
