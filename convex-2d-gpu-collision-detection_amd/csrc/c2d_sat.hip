@@ -102,6 +102,32 @@ __global__ __launch_bounds__(BLOCK) void sat_rect_verts_kernel(Planes16 P, size_
     if (d_count) wave_count_arrive(my_count, d_count, words);
 }
 
+// ---- rectangle pairs, array-of-rectangles format ----------------------------------------
+// The reference's own argument layout, convex_collide(float* r1, float* r2) with flat
+// float[8] rectangles (utils.cu:159), batched: r1, r2 are f32[n][8].  A lane reads its
+// pair as 4 x 16 B; a wave covers 2 x 2 KiB of contiguous memory, so the loads coalesce
+// as well as the SoA planes do (same 65 B/pair).
+__global__ __launch_bounds__(kBlock) void sat_rect_aos_kernel(const float* __restrict__ r1s, const float* __restrict__ r2s,
+                                                              size_t n, uint8_t* __restrict__ out,
+                                                              unsigned long long* __restrict__ d_count,
+                                                              unsigned long long* __restrict__ words)
+{
+    uint32_t my_count = 0;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const f32x4* a = reinterpret_cast<const f32x4*>(r1s) + 2 * i;
+        const f32x4* b = reinterpret_cast<const f32x4*>(r2s) + 2 * i;
+        const f32x4 a0 = __builtin_nontemporal_load(a), a1 = __builtin_nontemporal_load(a + 1);
+        const f32x4 b0 = __builtin_nontemporal_load(b), b1 = __builtin_nontemporal_load(b + 1);
+        const float r1[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        const float r2[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        const uint32_t c = rect_collide(r1, r2) ? 1u : 0u;
+        out[i] = (uint8_t)c;
+        my_count += c;
+    }
+    if (d_count) wave_count_arrive(my_count, d_count, words);
+}
+
 // ---- rectangle pairs, pose format (10 planes, 41 B/pair) ------------------------------
 // Same lane mapping as the vertex kernel (VEC == 4: one float4 per plane, 4 pairs
 // per lane); both rectangles are rebuilt per pair (2 sincos + 2 x 16 ops), which
@@ -363,6 +389,21 @@ int c2d_sat_rect_pairs_verts(c2d_ctx* ctx, const float* const d_planes[16], size
                            ctx->d_count_words);
         C2D_LAUNCH_CHECK(ctx);
     }
+    return C2D_OK;
+}
+
+int c2d_sat_rect_pairs_aos(c2d_ctx* ctx, const float* d_r1, const float* d_r2, size_t n, uint8_t* d_out,
+                           unsigned long long* d_count, c2d_stream stream)
+{
+    if (!ctx) return C2D_ERR_INVALID_ARG;
+    if (n == 0) return C2D_OK;
+    if (!d_r1 || !d_r2 || !d_out) return fail_arg(ctx, "c2d_sat_rect_pairs_aos: NULL argument");
+    if (!aligned_to(d_r1, 16) || !aligned_to(d_r2, 16)) return fail_arg(ctx, "c2d_sat_rect_pairs_aos: rectangle arrays must be 16-byte aligned");
+    DeviceGuard g(ctx->device);
+    const int grid = grid_for(n, kBlock, kMaxBlocks);
+    hipLaunchKernelGGL(sat_rect_aos_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, d_r1, d_r2, n, d_out, d_count,
+                       ctx->d_count_words);
+    C2D_LAUNCH_CHECK(ctx);
     return C2D_OK;
 }
 

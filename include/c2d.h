@@ -122,6 +122,13 @@ int c2d_rects_from_poses(c2d_ctx* ctx, const float* d_cx, const float* d_cy, con
 int c2d_sat_rect_pairs_verts(c2d_ctx* ctx, const float* const d_planes[16], size_t n,
                              uint8_t* d_out, unsigned long long* d_count, c2d_stream stream);
 
+/* c2d_sat_rect_pairs_aos: the same test on the reference's own argument layout,
+ * convex_collide(float* r1, float* r2) (utils.cu:159) with flat float[8]
+ * rectangles, batched: d_r1 and d_r2 are f32[n][8] (16-byte aligned), pair i is
+ * (d_r1 + 8*i, d_r2 + 8*i).  Same 65 B/pair as the plane format. */
+int c2d_sat_rect_pairs_aos(c2d_ctx* ctx, const float* d_r1, const float* d_r2, size_t n,
+                           uint8_t* d_out, unsigned long long* d_count, c2d_stream stream);
+
 /* c2d_sat_rect_pairs_pose: the same test on pose-format input: for each pair,
  * both rectangles are built on the fly exactly as c2d_rects_from_poses would
  * (utils.cu:119-142) and then tested (utils.cu:159-184).
