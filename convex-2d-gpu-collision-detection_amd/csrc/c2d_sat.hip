@@ -205,8 +205,8 @@ __global__ __launch_bounds__(kBlock) void rects_from_poses_kernel(const float* _
 // its axes from registers.  That register blocking is what matters: with one
 // axis per lane the kernel was bound by LDS instruction issue (one b128 read
 // per 10 VALU instructions on every SIMD), with four axes per lane it is one
-// read per 40.  Vertex lists are padded to an even length by repeating the
-// last vertex, which cannot change a min or a max.
+// read per 40.  The next pass's vertices are prefetched into registers while the
+// current pass is evaluated, so the global-load latency hides behind compute.
 constexpr int kPolyPairs = 64;                  // pairs staged per block pass
 constexpr int kPolyStride = 2 * C2D_POLY_KMAX;  // vertices per pair slot (A then B) = max axes per pair
 constexpr int kPolyPitch = kPolyStride + 2;     // float2 per pair slot: 272 B = 17 x 16 B keeps b128 reads
@@ -237,29 +237,37 @@ __global__ __launch_bounds__(kBlock) void sat_poly_kernel(const float* __restric
     const int group = tid / kPolyLanes;  // which pair of the current group of kBlock / kPolyLanes
     const int l = tid % kPolyLanes;      // lane within the pair
     const size_t n_pass = (n + kPolyPairs - 1) / kPolyPairs;
-    for (size_t pass = blockIdx.x; pass < n_pass; pass += gridDim.x) {
+    // Register prefetch of the next pass: thread t stages pair j = t % 64, vertex rows
+    // t/64, t/64 + 4, ... (8 rows) and, for t < 128, one vertex count.  All 32 vertex slots of the
+    // padded layout are read, so the loads depend on nothing and fly during the previous pass.
+    constexpr int kRows = kPolyStride / (kBlock / kPolyPairs);  // rows per thread = 8
+    const int sj = tid & (kPolyPairs - 1);
+    const int row0 = tid / kPolyPairs;
+    float px[kRows], py[kRows];
+    uint8_t pk = 0;
+    auto prefetch = [&](size_t pass) {
+        const size_t base = pass * kPolyPairs;
+        const bool in = base + sj < n;
+#pragma unroll
+        for (int i = 0; i < kRows; i++) {
+            const int row = row0 + i * (kBlock / kPolyPairs);
+            const size_t idx = (size_t)row * n + base + sj;  // row = polygon * KMAX + vertex
+            px[i] = in ? __builtin_nontemporal_load(vx + idx) : 0.0f;
+            py[i] = in ? __builtin_nontemporal_load(vy + idx) : 0.0f;
+        }
+        if (tid < 2 * kPolyPairs) pk = in ? kcnt[(size_t)(tid / kPolyPairs) * n + base + sj] : (uint8_t)0;
+    };
+    size_t pass = blockIdx.x;
+    if (pass < n_pass) prefetch(pass);
+    for (; pass < n_pass; pass += gridDim.x) {
         const size_t base = pass * kPolyPairs;
         const int pairs_here = (int)((n - base) < (size_t)kPolyPairs ? (n - base) : (size_t)kPolyPairs);
         __syncthreads();  // previous pass finished reading LDS
-        if (tid < 2 * kPolyPairs) {
-            int p = tid / kPolyPairs, j = tid % kPolyPairs;
-            s_k[p][j] = j < pairs_here ? kcnt[(size_t)p * n + base + j] : (uint8_t)0;
-        }
+#pragma unroll
+        for (int i = 0; i < kRows; i++) s_v[sj][row0 + i * (kBlock / kPolyPairs)] = make_float2(px[i], py[i]);
+        if (tid < 2 * kPolyPairs) s_k[tid / kPolyPairs][sj] = pk;
         __syncthreads();
-        // stage: thread t loads pair j = t % 64 for rows (p,v) = t/64, t/64+4, ...
-        {
-            const int j = tid & (kPolyPairs - 1);
-            for (int row = tid / kPolyPairs; row < kPolyStride; row += kBlock / kPolyPairs) {
-                const int p = row / C2D_POLY_KMAX, v = row % C2D_POLY_KMAX;
-                const int kp = (int)s_k[p][j];
-                if (j < pairs_here && v < ((kp + 1) & ~1)) {       // the vertices and one pad slot
-                    const int vv = v < kp ? v : kp - 1;            // pad = copy of the last vertex
-                    const size_t idx = ((size_t)p * C2D_POLY_KMAX + vv) * n + base + j;
-                    s_v[j][row] = make_float2(vx[idx], vy[idx]);
-                }
-            }
-        }
-        __syncthreads();
+        if (pass + gridDim.x < n_pass) prefetch(pass + gridDim.x);
         // evaluate: kBlock / kPolyLanes pairs at a time
         for (int j0 = 0; j0 < pairs_here; j0 += kBlock / kPolyLanes) {
             const int j = j0 + group;
@@ -287,7 +295,8 @@ __global__ __launch_bounds__(kBlock) void sat_poly_kernel(const float* __restric
             }
             const float4* A4 = reinterpret_cast<const float4*>(A);
             const float4* B4 = reinterpret_cast<const float4*>(B);
-            for (int k = 0; 2 * k < ka; k++) {
+            // two vertices per ds_read_b128; an odd count ends with one single vertex
+            for (int k = 0; 2 * k + 1 < ka; k++) {
                 const float4 q = A4[k];
 #pragma unroll
                 for (int r = 0; r < kPolyAxes; r++) {
@@ -295,13 +304,23 @@ __global__ __launch_bounds__(kBlock) void sat_poly_kernel(const float* __restric
                     minmax_update(nx[r], ny[r], q.z, q.w, min1[r], max1[r]);
                 }
             }
-            for (int k = 0; 2 * k < kb; k++) {
+            if (ka & 1) {
+                const float2 q = A[ka - 1];
+#pragma unroll
+                for (int r = 0; r < kPolyAxes; r++) minmax_update(nx[r], ny[r], q.x, q.y, min1[r], max1[r]);
+            }
+            for (int k = 0; 2 * k + 1 < kb; k++) {
                 const float4 q = B4[k];
 #pragma unroll
                 for (int r = 0; r < kPolyAxes; r++) {
                     minmax_update(nx[r], ny[r], q.x, q.y, min2[r], max2[r]);
                     minmax_update(nx[r], ny[r], q.z, q.w, min2[r], max2[r]);
                 }
+            }
+            if (kb & 1) {
+                const float2 q = B[kb - 1];
+#pragma unroll
+                for (int r = 0; r < kPolyAxes; r++) minmax_update(nx[r], ny[r], q.x, q.y, min2[r], max2[r]);
             }
             bool sep = false;
 #pragma unroll
