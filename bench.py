@@ -346,6 +346,8 @@ def main() -> None:
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cpu as oracle  # checker / reported baseline only
 
+        oracle.set_num_threads(oracle.usable_cores())  # the box's CPU share, not the host's thread count
+
         m = min(n, 2_000_000)
         host_planes = planes[:, :m].contiguous().cpu().numpy()
         gpu_out = out[:m].cpu().numpy()

@@ -86,6 +86,32 @@ def num_threads() -> int:
     return lib().c2d_oracle_num_threads()
 
 
+def usable_cores() -> int:
+    """CPU cores this process may actually use: the affinity mask capped by the cgroup CPU quota
+    (a GPU box hands a 1-GPU job a 16-core share of a 128-thread host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def set_num_threads(n: int) -> int:
+    lib().c2d_oracle_set_num_threads(int(n))
+    return num_threads()
+
+
 def logf(u):
     u = _f32(np.atleast_1d(u))
     return np.array([lib().c2d_oracle_logf(float(v)) for v in u], dtype=np.float32)
