@@ -54,6 +54,21 @@ typedef struct PoseCPVarAndPoseIdx {
 /* Arbitrary convex polygons carry at most this many vertices (BASELINE config 5). */
 #define C2D_POLY_KMAX 16
 
+/* create_rect (reference utils.cu:119-130, a __device__ __host__ function the reference's mains
+ * call on the host, e.g. compute_collision_probability.cu:240): the 4 counter-clockwise vertices
+ * of a w x h box centred at the origin, starting at (-w/2, -h/2). */
+static inline void create_rect(float* r, float w, float h)
+{
+    r[0] = -w / 2;
+    r[1] = -h / 2;
+    r[2] = w / 2;
+    r[3] = -h / 2;
+    r[4] = w / 2;
+    r[5] = h / 2;
+    r[6] = -w / 2;
+    r[7] = h / 2;
+}
+
 #ifdef __cplusplus
 }
 #endif

@@ -140,6 +140,24 @@ def test_razor_edge_pairs(eng, oracle):
     assert np.array_equal(out, ref) and cnt == ref_cnt
 
 
+def test_extreme_magnitudes_and_denormals(eng, oracle):
+    """Vertices spanning 2^-149 .. 2^60 (subnormals included), plus exact zeros and signed zeros:
+    the GPU must keep subnormals (no flush-to-zero) and order +-0 like the oracle does."""
+    rng = np.random.default_rng(99)
+    n = 200_000
+    mag = np.exp2(rng.uniform(-149, 60, (16, n)))
+    planes = (mag * rng.choice([-1.0, 1.0], (16, n))).astype(np.float32)
+    planes[:, : n // 10][rng.random((16, n // 10)) < 0.3] = 0.0
+    planes[:, n // 10: n // 5][rng.random((16, n // 5 - n // 10)) < 0.3] = -0.0
+    # a block where everything is subnormal or tiny, so that products underflow
+    planes[:, n // 2: n // 2 + 20000] = (np.exp2(rng.uniform(-149, -120, (16, 20000))) * rng.choice([-1.0, 1.0], (16, 20000))).astype(np.float32)
+    assert np.isfinite(planes).all() and (np.abs(planes[planes != 0]) < 1e-38).any()
+    ref, ref_cnt = oracle.sat_rect_pairs_verts(planes)
+    out, cnt = run_verts(eng, planes)
+    assert np.array_equal(out, ref) and cnt == ref_cnt
+    assert 0 < ref_cnt < n
+
+
 def test_full_size_properties_1e7(eng, wl):
     """BASELINE config 2 size (1e7 pairs): size-independent properties.
     collide(a,b) == collide(b,a); collide is invariant under a cyclic shift of

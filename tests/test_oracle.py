@@ -227,3 +227,23 @@ def test_sample_scenes_distribution(oracle, wl):
     assert len(np.unique(s["pose_idx"])) > 50
     r = np.hypot(s["x"], s["y"])
     assert 2.0 < np.median(r) < 12.0
+
+
+def test_hypothesis_numpy_and_c_oracles_agree_on_arbitrary_floats(oracle):
+    """Property test over arbitrary finite vertex values (subnormals, zeros, large magnitudes):
+    the numpy and C restatements agree, and the answer is symmetric in the two rectangles."""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+    from hypothesis.extra.numpy import arrays
+
+    f = st.floats(min_value=-float(2**50), max_value=float(2**50), allow_nan=False, allow_infinity=False, width=32)
+
+    @settings(max_examples=300, deadline=None)
+    @given(arrays(np.float32, (8,), elements=f), arrays(np.float32, (8,), elements=f))
+    def check(r1, r2):
+        c = oracle.convex_collide(r1, r2)
+        assert c == sat.convex_collide_scalar(r1, r2)
+        assert c == int(sat.convex_collide(r1[None, :], r2[None, :])[0])
+        assert c == oracle.convex_collide(r2, r1)
+
+    check()
