@@ -64,7 +64,8 @@ def test_canonical_math_bit_exact(eng, oracle):
     g0, _, r0, _ = _math_both(eng, oracle, eng.MATH_LOG, u.view(np.uint32))
     assert np.array_equal(g0, r0)
     # sin/cos of float angles incl. large ones, and of integer angles incl. octant boundaries
-    th = np.concatenate([rng.uniform(-10, 10, 4_000_000), rng.uniform(-1e5, 1e5, 1_000_000), [0.0, -0.0, np.pi / 4, np.pi / 2, np.pi]]).astype(np.float32)
+    th = np.concatenate([rng.uniform(-10, 10, 4_000_000), rng.uniform(-1e5, 1e5, 1_000_000), rng.uniform(-1e9, 1e9, 500_000),
+                         10.0 ** rng.uniform(-40, 15, 500_000), [0.0, -0.0, np.pi / 4, np.pi / 2, np.pi, 1e15, -1e15]]).astype(np.float32)
     g0, g1, r0, r1 = _math_both(eng, oracle, eng.MATH_SINCOS, th.view(np.uint32))
     assert np.array_equal(g0, r0) and np.array_equal(g1, r1)
     y = np.concatenate([rng.integers(0, 2**32, 5_000_000, dtype=np.uint64).astype(np.uint32),
