@@ -28,7 +28,13 @@ struct Scene {
     float robot[8];       // robot rectangle in the obstacle frame
     float hw, hh;         // obstacle half extents (create_rect: +-w/2, +-h/2)
     float sx, sy, st, sw, sh;  // standard deviations (StdDev)
+    // Certain-separation pretest on the obstacle centre alone (see centre_pretest)
+    float pax[2], pay[2], plo[2], phi[2];
 };
+
+// |N(0,1) draw| of box_muller: the radius is at most sqrt(-2 ln 2^-33) = 6.7638 and
+// |sin|, |cos| <= 1 + 2^-22.
+constexpr float kNormalMax = 6.77f;
 
 C2D_DEV Scene make_scene(float robot_w, float robot_h, float px, float py, const Pose& pose, const StdDev& sd)
 {
@@ -39,19 +45,70 @@ C2D_DEV Scene make_scene(float robot_w, float robot_h, float px, float py, const
     sc.hw = pose.width / 2;                                                    // ccp.cu:128
     sc.hh = pose.height / 2;
     sc.sx = sd.x; sc.sy = sd.y; sc.st = sd.theta; sc.sw = sd.width; sc.sh = sd.height;
+
+    // ---- certain-separation pretest ------------------------------------------------
+    // Every vertex of a sampled obstacle is  centre + w  with centre = (dx, dy) and
+    // |w| <= rho = sqrt(hx^2 + hy^2) whatever the rotation, where |hx| <= |hw| + 3.385|sw|
+    // and |hy| <= |hh| + 3.385|sh| (|draw| <= kNormalMax).  On robot axis a the SAT compares
+    // the obstacle's projections a.o_k with the robot's own interval [rmin, rmax] (the very
+    // floats computed below).  With T = a.centre,
+    //     a.o_k  >=  T - |a|_2 rho - err,     a.o_k  <=  T + |a|_2 rho + err,
+    // err = all fp32 roundings on the way (vertex construction ~6u |a|_2 rho, final adds and
+    // the dot products ~8u |a|_1 (rho + D), the evaluation of T ~3u |a|_1 D; u = 2^-24,
+    // D >= |dx| + |dy|).  The margin M below grants 2^-10 |a|_2 rho + 2^-12 |a|_1 (rho + D),
+    // over 500 times that, and the thresholds are pushed outwards by another 2^-20 relative.
+    // Hence T > phi or T < plo on either axis proves that convex_collide would find that
+    // axis separating: the sample is a certain miss and nothing else of it needs evaluating.
+    const float hxm = __builtin_fabsf(sc.hw) + 0.5f * kNormalMax * __builtin_fabsf(sc.sw);
+    const float hym = __builtin_fabsf(sc.hh) + 0.5f * kNormalMax * __builtin_fabsf(sc.sh);
+    const float rho = __builtin_sqrtf(hxm * hxm + hym * hym);
+    const float D = kNormalMax * (__builtin_fabsf(sc.sx) + __builtin_fabsf(sc.sy));
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const float ax = sc.robot[2 * i + 2] - sc.robot[2 * i];
+        const float ay = sc.robot[2 * i + 3] - sc.robot[2 * i + 1];
+        const float p0 = ax * sc.robot[0] + ay * sc.robot[1], p1 = ax * sc.robot[2] + ay * sc.robot[3];
+        const float p2 = ax * sc.robot[4] + ay * sc.robot[5], p3 = ax * sc.robot[6] + ay * sc.robot[7];
+        const float rmin = min4(p0, p1, p2, p3), rmax = max4(p0, p1, p2, p3);
+        const float n2 = __builtin_sqrtf(ax * ax + ay * ay), n1 = __builtin_fabsf(ax) + __builtin_fabsf(ay);
+        const float M = (n2 * rho) * (1.0f + 0x1p-10f) + 0x1p-12f * (n1 * (rho + D));
+        const float hi = rmax + M, lo = rmin - M;
+        sc.pax[i] = ax;
+        sc.pay[i] = ay;
+        sc.phi[i] = hi + 0x1p-20f * __builtin_fabsf(hi);
+        sc.plo[i] = lo - 0x1p-20f * __builtin_fabsf(lo);
+    }
     return sc;
 }
 
-// The sampled obstacle of one sample (reference utils.cu:144-157).  The second
-// Philox block only feeds dh; it is skipped when sigma_h == 0 because dh = n*0
-// cannot change any vertex (the product is +-0 and is only ever added).
-C2D_DEV void sample_obstacle(const Scene& sc, uint64_t seed, uint64_t scene_id, uint64_t sample, float (&o)[8])
+// true: this sample certainly does not collide (proof in make_scene); false: unknown.
+// Non-finite thresholds compare false, i.e. "unknown".
+C2D_DEV bool centre_pretest(const Scene& sc, float dx, float dy)
 {
-    const U4 a = philox_block(seed, scene_id, sample, 0);
-    float n0, n1, n2, n3;
+    const float t0 = fma_(sc.pax[0], dx, sc.pay[0] * dy);
+    const float t1 = fma_(sc.pax[1], dx, sc.pay[1] * dy);
+    return (t0 > sc.phi[0]) | (t0 < sc.plo[0]) | (t1 > sc.phi[1]) | (t1 < sc.plo[1]);
+}
+
+// The sampled obstacle of one sample (reference utils.cu:144-157), in two steps: the first
+// Philox block and its first Box-Muller pair give the centre (dx, dy); the rest (dtheta, dw,
+// dh, rotation, vertices) is only needed when the centre pretest cannot rule the sample out.
+// The second Philox block only feeds dh; it is skipped when sigma_h == 0 because dh = n*0
+// cannot change any vertex (the product is +-0 and is only ever added).
+C2D_DEV void sample_centre(const Scene& sc, const U4& a, float& dx, float& dy)
+{
+    float n0, n1;
     box_muller(a.x, a.y, n0, n1);
+    dx = n0 * sc.sx;
+    dy = n1 * sc.sy;
+}
+
+C2D_DEV void sample_obstacle(const Scene& sc, const U4& a, float dx, float dy, uint64_t seed, uint64_t scene_id,
+                             uint64_t sample, float (&o)[8])
+{
+    float n2, n3;
     box_muller(a.z, a.w, n2, n3);
-    const float dx = n0 * sc.sx, dy = n1 * sc.sy, dt = n2 * sc.st, dw = n3 * sc.sw;
+    const float dt = n2 * sc.st, dw = n3 * sc.sw;
     float dh = 0.0f;
     if (sc.sh != 0.0f) {  // wave-uniform
         const U4 b = philox_block(seed, scene_id, sample, 1);
@@ -99,12 +156,25 @@ C2D_DEV bool sample_collides(const Scene& sc, const float (&o)[8])
 C2D_DEV uint32_t wave_count_hits(const Scene& sc, uint64_t seed, uint64_t scene_id, uint64_t begin, uint32_t count)
 {
     const uint32_t lane = threadIdx.x & 63;
-    uint32_t hits = 0;  // wave-uniform (scalar) accumulator
+    uint32_t hits = 0;      // wave-uniform (scalar) accumulator
+    uint32_t holdoff = 0;   // iterations to run without the pretest after it failed to clear a wave
     for (uint32_t off = 0; off < count; off += 64) {
         const uint32_t idx = off + lane;
+        const bool in_range = idx < count;
+        const U4 a = philox_block(seed, scene_id, begin + idx, 0);
+        float dx, dy;
+        sample_centre(sc, a, dx, dy);
+        if (holdoff == 0) {
+            // all 64 samples certain misses: skip the second Box-Muller pair, the rotation,
+            // the vertices and the SAT (most iterations of a far scene)
+            if (__ballot(in_range && !centre_pretest(sc, dx, dy)) == 0ull) continue;
+            holdoff = 8;  // near scene: do not pay for the test every iteration
+        } else {
+            holdoff--;
+        }
         float o[8];
-        sample_obstacle(sc, seed, scene_id, begin + idx, o);
-        const bool hit = sample_collides(sc, o) && idx < count;
+        sample_obstacle(sc, a, dx, dy, seed, scene_id, begin + idx, o);
+        const bool hit = sample_collides(sc, o) && in_range;
         hits += (uint32_t)__popcll(__ballot(hit));
     }
     return hits;

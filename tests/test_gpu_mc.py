@@ -99,6 +99,28 @@ def test_mc_pair_shape_variance_and_zero_sigma(eng, oracle):
         assert got == oracle.mc_pair(W, H, pos, pose, sd, 77, 1, 0, 50000), sd
 
 
+def test_mc_centre_pretest_boundary_sweep(eng, oracle):
+    """The kernels skip a wave's samples when the obstacle centres alone prove a miss (bounding-disk
+    argument in make_scene).  Sweep the robot through the region where that shortcut starts to fire —
+    from clearly colliding to clearly apart, several orientations, with and without shape variance —
+    and require the exact hit count of the oracle, which has no shortcut."""
+    rng = np.random.default_rng(8)
+    n = 150_000
+    cases = 0
+    for sd in [(0.3, 0.3, 0.2, 0.0, 0.0), (0.05, 0.4, 0.6, 0.0, 0.0), (0.2, 0.1, 0.1, 0.3, 0.2), (1e-3, 1e-3, 0.5, 0.0, 0.0)]:
+        for pose_theta in (0.0, 0.6, 1.3):
+            pose = (2.0, 1.0, pose_theta)
+            rho = float(np.hypot(1.0 + 3.385 * sd[3], 0.5 + 3.385 * sd[4]))
+            for dist in list(np.linspace(2.0, 2.035 + rho + 3.0, 9)) + [2.035 + rho * (1 + 2.0**-10) + k * 1e-4 for k in (-2, 0, 2)]:
+                ang = float(rng.uniform(-0.4, 0.4))
+                pos = (float(dist * np.cos(ang)), float(dist * np.sin(ang)))
+                sid = cases
+                got = gpu_hits(eng, pos, pose, sd, 2024, sid, 0, n)
+                assert got == oracle.mc_pair(W, H, pos, pose, sd, 2024, sid, 0, n), (sd, pose, pos)
+                cases += 1
+    assert cases == 4 * 3 * 12
+
+
 def test_mc_pair_range_additivity_and_accumulation(eng, wl):
     """Disjoint sample ranges sum to the whole (this is what sharding over GPUs relies on),
     and d_hits accumulates across calls."""
