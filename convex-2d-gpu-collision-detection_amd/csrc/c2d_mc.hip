@@ -152,6 +152,9 @@ C2D_DEV bool sample_collides(const Scene& sc, const float (&o)[8])
     return !sep;
 }
 
+#ifndef C2D_MC_PRETEST_HOLDOFF
+#define C2D_MC_PRETEST_HOLDOFF 3
+#endif
 // hits among samples [begin, begin + count) of one scene, computed by one wave
 C2D_DEV uint32_t wave_count_hits(const Scene& sc, uint64_t seed, uint64_t scene_id, uint64_t begin, uint32_t count)
 {
@@ -168,7 +171,7 @@ C2D_DEV uint32_t wave_count_hits(const Scene& sc, uint64_t seed, uint64_t scene_
             // all 64 samples certain misses: skip the second Box-Muller pair, the rotation,
             // the vertices and the SAT (most iterations of a far scene)
             if (__ballot(in_range && !centre_pretest(sc, dx, dy)) == 0ull) continue;
-            holdoff = 8;  // near scene: do not pay for the test every iteration
+            holdoff = C2D_MC_PRETEST_HOLDOFF;  // near scene: do not pay for the test every iteration
         } else {
             holdoff--;
         }
