@@ -103,11 +103,11 @@ C2D_DEV void sample_centre(const Scene& sc, const U4& a, float& dx, float& dy)
     dy = n1 * sc.sy;
 }
 
-C2D_DEV void sample_obstacle(const Scene& sc, const U4& a, float dx, float dy, uint64_t seed, uint64_t scene_id,
-                             uint64_t sample, float (&o)[8])
+C2D_DEV void sample_obstacle(const Scene& sc, uint32_t az, uint32_t aw, float dx, float dy, uint64_t seed,
+                             uint64_t scene_id, uint64_t sample, float (&o)[8])
 {
     float n2, n3;
-    box_muller(a.z, a.w, n2, n3);
+    box_muller(az, aw, n2, n3);
     const float dt = n2 * sc.st, dw = n3 * sc.sw;
     float dh = 0.0f;
     if (sc.sh != 0.0f) {  // wave-uniform
@@ -155,30 +155,65 @@ C2D_DEV bool sample_collides(const Scene& sc, const float (&o)[8])
 #ifndef C2D_MC_PRETEST_HOLDOFF
 #define C2D_MC_PRETEST_HOLDOFF 3
 #endif
+constexpr int kQueueSlots = 128;  // per wave: < 64 left over + at most 64 pushed per iteration
+
+// Per-wave queue of samples the centre pretest could not rule out.  A far or mid-range scene
+// rules out most samples of an iteration but rarely all 64, and a SIMD wave pays for the full
+// evaluation as soon as one lane needs it; so undecided samples are parked here (centre, the two
+// unused Philox words, sample offset) and evaluated 64 at a time, all lanes busy.
+struct WaveQueue {
+    float4 cw[kQueueSlots];      // dx, dy, bits(a.z), bits(a.w)
+    uint32_t idx[kQueueSlots];   // sample offset within the chunk
+};
+
 // hits among samples [begin, begin + count) of one scene, computed by one wave
-C2D_DEV uint32_t wave_count_hits(const Scene& sc, uint64_t seed, uint64_t scene_id, uint64_t begin, uint32_t count)
+C2D_DEV uint32_t wave_count_hits(const Scene& sc, uint64_t seed, uint64_t scene_id, uint64_t begin, uint32_t count,
+                                 WaveQueue& q)
 {
     const uint32_t lane = threadIdx.x & 63;
-    uint32_t hits = 0;      // wave-uniform (scalar) accumulator
-    uint32_t holdoff = 0;   // iterations to run without the pretest after it failed to clear a wave
-    for (uint32_t off = 0; off < count; off += 64) {
-        const uint32_t idx = off + lane;
-        const bool in_range = idx < count;
-        const U4 a = philox_block(seed, scene_id, begin + idx, 0);
-        float dx, dy;
-        sample_centre(sc, a, dx, dy);
-        if (holdoff == 0) {
-            // all 64 samples certain misses: skip the second Box-Muller pair, the rotation,
-            // the vertices and the SAT (most iterations of a far scene)
-            if (__ballot(in_range && !centre_pretest(sc, dx, dy)) == 0ull) continue;
-            holdoff = C2D_MC_PRETEST_HOLDOFF;  // near scene: do not pay for the test every iteration
-        } else {
-            holdoff--;
+    uint32_t hits = 0;    // wave-uniform (scalar) accumulator
+    uint32_t qn = 0;      // queued samples (wave-uniform)
+    uint32_t dense = 0;   // iterations to evaluate in place after the pretest ruled nothing out
+    // one trip beyond the last samples flushes what is left in the queue
+    for (uint32_t off = 0; off < count + 64; off += 64) {
+        const bool flush = off >= count;
+        if (!flush) {
+            const uint32_t idx = off + lane;
+            const bool in_range = idx < count;
+            const U4 a = philox_block(seed, scene_id, begin + idx, 0);
+            float dx, dy;
+            sample_centre(sc, a, dx, dy);
+            if (dense) {  // near scene: every lane needs the full evaluation anyway
+                dense--;
+                float o[8];
+                sample_obstacle(sc, a.z, a.w, dx, dy, seed, scene_id, begin + idx, o);
+                hits += (uint32_t)__popcll(__ballot(sample_collides(sc, o) && in_range));
+                continue;
+            }
+            const bool undecided = in_range && !centre_pretest(sc, dx, dy);
+            const unsigned long long m = __ballot(undecided);
+            if (m == 0ull) continue;  // the common case of a far scene: 64 certain misses
+            if (m == ~0ull) dense = C2D_MC_PRETEST_HOLDOFF;
+            if (undecided) {
+                const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                q.cw[pos] = make_float4(dx, dy, __uint_as_float(a.z), __uint_as_float(a.w));
+                q.idx[pos] = idx;
+            }
+            qn += (uint32_t)__popcll(m);
+            if (qn < 64) continue;
+        } else if (qn == 0) {
+            break;
         }
+        // evaluate 64 queued samples (the last qn on the flush trip)
+        const uint32_t take = qn < 64 ? qn : 64;
+        const bool live = lane < take;
+        const uint32_t src = qn - take + (live ? lane : 0);
+        const float4 e = q.cw[src];
+        const uint32_t eidx = q.idx[src];
+        qn -= take;
         float o[8];
-        sample_obstacle(sc, a, dx, dy, seed, scene_id, begin + idx, o);
-        const bool hit = sample_collides(sc, o) && in_range;
-        hits += (uint32_t)__popcll(__ballot(hit));
+        sample_obstacle(sc, __float_as_uint(e.z), __float_as_uint(e.w), e.x, e.y, seed, scene_id, begin + eidx, o);
+        hits += (uint32_t)__popcll(__ballot(sample_collides(sc, o) && live));
     }
     return hits;
 }
@@ -194,6 +229,7 @@ struct PairArgs {
 
 __global__ __launch_bounds__(kMcBlock) void mc_pair_kernel(PairArgs A, unsigned long long* __restrict__ d_hits)
 {
+    __shared__ WaveQueue s_queue[kWavesPerBlock];
     const Scene sc = make_scene(A.robot_w, A.robot_h, A.px, A.py, A.pose, A.sd);
     const uint64_t n_chunks = (A.n_samples + A.chunk - 1) / A.chunk;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -202,7 +238,7 @@ __global__ __launch_bounds__(kMcBlock) void mc_pair_kernel(PairArgs A, unsigned 
         const uint64_t off = ch * A.chunk;
         const uint64_t left = A.n_samples - off;
         const uint32_t count = left < A.chunk ? (uint32_t)left : A.chunk;
-        total += wave_count_hits(sc, A.seed, A.scene_id, A.sample_begin + off, count);
+        total += wave_count_hits(sc, A.seed, A.scene_id, A.sample_begin + off, count, s_queue[wave]);
     }
     if ((threadIdx.x & 63) == 0 && total) atomicAdd(d_hits, total);
 }
@@ -258,6 +294,7 @@ __global__ void mc_scenes_init_kernel(AdaptiveState* state, uint32_t n_scenes)
 
 __global__ __launch_bounds__(kMcBlock) void mc_scenes_advance_kernel(ScenesArgs A)
 {
+    __shared__ WaveQueue s_queue[kWavesPerBlock];
     const uint32_t n_active = A.state->n_active;
     if (n_active == 0) return;
     const uint32_t n_start = A.state->n_samples;
@@ -291,7 +328,7 @@ __global__ __launch_bounds__(kMcBlock) void mc_scenes_advance_kernel(ScenesArgs 
         const Pose pose = A.poses[pi];
         const StdDev sd = A.std_devs[vi];
         const Scene sc = make_scene(A.robot_w, A.robot_h, row.x, row.y, pose, sd);
-        const uint32_t h = wave_count_hits(sc, A.seed, A.scene_id_base + g, (uint64_t)n_start + off, count);
+        const uint32_t h = wave_count_hits(sc, A.seed, A.scene_id_base + g, (uint64_t)n_start + off, count, s_queue[wave]);
         if ((threadIdx.x & 63) == 0 && h) atomicAdd(&A.hits[g], h);
     }
 }
