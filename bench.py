@@ -35,7 +35,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_PAIR = 65            # 16 planes x 4 B read + 1 B written
 FP32_VALU_PEAK_TFLOPS = 157.3  # spec, FMA counted as 2
-VALU_INSTR_PER_SAMPLE = 432    # MC sample loop, sigma_h = 0, all 8 axes (counted in the gfx950 ISA)
+VALU_INSTR_PER_SAMPLE = 342    # config-3 scene: SQ_INSTS_VALU x 64 / samples (profiles/r01d_pmc_sq.txt); a fully
+                               # evaluated sample costs 432, one ruled out by its centre alone about 105
 KMAX = 16
 
 
@@ -272,7 +273,7 @@ def main() -> None:
               "bound": "valu", "note": "~0 HBM bytes per sample; VALU/transcendental bound (DESIGN.md)"}
 
     if mc is not None:
-        # VALU instructions per sample in the sample loop (counted in the gfx950 ISA)
+        # average VALU instructions per sample of this scene, measured with the SQ_INSTS_VALU counter
         lane_ops = mc["value"] / world * VALU_INSTR_PER_SAMPLE / 1e12
         mc["roofline"] = {"bound": "valu", "achieved": round(lane_ops, 2), "peak": FP32_VALU_PEAK_TFLOPS / 2,
                           "unit": "T VALU lane-instr/s per GPU (peak = 157.3 TFLOP/s / 2 flop per FMA)",
