@@ -30,6 +30,9 @@ struct Scene {
     float sx, sy, st, sw, sh;  // standard deviations (StdDev)
     // Certain-separation pretest on the obstacle centre alone (see centre_pretest)
     float pax[2], pay[2], plo[2], phi[2];
+    // Radius-only form of the same pretest: raw word x >= x0 (and use_x0) proves a miss
+    uint32_t x0;
+    bool use_x0;
 };
 
 // |N(0,1) draw| of box_muller: the radius is at most sqrt(-2 ln 2^-33) = 6.7638 and
@@ -77,6 +80,36 @@ C2D_DEV Scene make_scene(float robot_w, float robot_h, float px, float py, const
         sc.pay[i] = ay;
         sc.phi[i] = hi + 0x1p-20f * __builtin_fabsf(hi);
         sc.plo[i] = lo - 0x1p-20f * __builtin_fabsf(lo);
+    }
+
+    // ---- the same pretest from the Box-Muller radius alone -----------------------------
+    // T_i = pax_i dx + pay_i dy with dx = sin * rad * sx, dy = cos * rad * sy, so
+    // |T_i| <= rad * G_i (1 + 2^-10), G_i = sqrt((pax_i sx)^2 + (pay_i sy)^2)   (sin^2 + cos^2 <=
+    // 1 + 2^-21 for the canonical pair; the slack covers every rounding).  If the robot's widened
+    // slab i does not contain the obstacle's mean centre (the origin) — plo_i > 0 or phi_i < 0 —
+    // then rad < L_i / (G_i (1 + 2^-10)) with L_i = plo_i resp. -phi_i already proves the miss.
+    // rad = sqrt(-2 log u) falls with u = (x + 1/2) 2^-32, so "rad < R0" is "x >= x0" for the
+    // raw word x: one integer compare decides the sample before any transcendental is evaluated.
+    // x0 is rounded up generously: u0 = exp(-(R0 (1 - 2^-10))^2 / 2), x0 = u0 (1 + 2^-10) 2^32 + 2.
+    float R0 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const float gx = sc.pax[i] * sc.sx, gy = sc.pay[i] * sc.sy;
+        const float G = __builtin_sqrtf(gx * gx + gy * gy) * (1.0f + 0x1p-10f);
+        const float L = sc.plo[i] > 0.0f ? sc.plo[i] : (sc.phi[i] < 0.0f ? -sc.phi[i] : 0.0f);
+        if (L > 0.0f && G > 0.0f) R0 = __builtin_fmaxf(R0, L / G);
+        // G == 0 (sigma_x = sigma_y = 0) leaves T_i = 0: centre_pretest itself decides that case
+    }
+    sc.use_x0 = false;
+    sc.x0 = 0xffffffffu;
+    if (R0 > 0.25f && R0 < 1e30f) {  // below 0.25 fewer than 3 % of the draws would qualify anyway
+        const float r = R0 * (1.0f - 0x1p-10f);
+        const float u0 = __expf(-0.5f * r * r) * (1.0f + 0x1p-10f);  // fast exp: error 2^-21 relative, inside the slack
+        const float xf = u0 * 4294967296.0f + 2.0f;
+        if (xf < 4294967040.0f) {
+            sc.x0 = (uint32_t)xf + 1u;
+            sc.use_x0 = true;
+        }
     }
     return sc;
 }
@@ -181,6 +214,8 @@ C2D_DEV uint32_t wave_count_hits(const Scene& sc, uint64_t seed, uint64_t scene_
             const uint32_t idx = off + lane;
             const bool in_range = idx < count;
             const U4 a = philox_block(seed, scene_id, begin + idx, 0);
+            // radius-only pretest: every in-range lane's radius word already proves a miss
+            if (sc.use_x0 && dense == 0 && __ballot(in_range && a.x < sc.x0) == 0ull) continue;
             float dx, dy;
             sample_centre(sc, a, dx, dy);
             if (dense) {  // near scene: every lane needs the full evaluation anyway
