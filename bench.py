@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_PAIR = 65            # 16 planes x 4 B read + 1 B written
 FP32_VALU_PEAK_TFLOPS = 157.3  # spec, FMA counted as 2
-VALU_INSTR_PER_SAMPLE = 342    # config-3 scene: SQ_INSTS_VALU x 64 / samples (profiles/r01d_pmc_sq.txt); a fully
+VALU_INSTR_PER_SAMPLE = 343    # config-3 scene: SQ_INSTS_VALU x 64 / samples (profiles/r01e_pmc_sq.txt); a fully
                                # evaluated sample costs 432, one ruled out by its centre alone about 105
 KMAX = 16
 
