@@ -45,3 +45,8 @@ TOOLS := $(CSRC)/tools/sat_tune
 tools: $(TOOLS)
 $(CSRC)/tools/%: $(CSRC)/tools/%.hip $(HDRS)
 	$(HIPCC) -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -Iinclude $< -o $@
+
+# validation build: Monte-Carlo kernels without the certain-miss pretests (tools/validate_pretest.py)
+lib-nopretest: $(LIBDIR)/libc2d.so
+	$(HIPCC) $(HIPFLAGS) -DC2D_MC_NO_PRETEST -c $(CSRC)/c2d_mc.hip -o $(CSRC)/c2d_mc_nopretest.o
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $(LIBDIR)/libc2d_nopretest.so $(CSRC)/c2d_api.o $(CSRC)/c2d_sat.o $(CSRC)/c2d_mc_nopretest.o

@@ -215,7 +215,9 @@ C2D_DEV uint32_t wave_count_hits(const Scene& sc, uint64_t seed, uint64_t scene_
             const bool in_range = idx < count;
             const U4 a = philox_block(seed, scene_id, begin + idx, 0);
             // radius-only pretest: every in-range lane's radius word already proves a miss
+#ifndef C2D_MC_NO_PRETEST  // validation builds evaluate every sample in full
             if (sc.use_x0 && dense == 0 && __ballot(in_range && a.x < sc.x0) == 0ull) continue;
+#endif
             float dx, dy;
             sample_centre(sc, a, dx, dy);
             if (dense) {  // near scene: every lane needs the full evaluation anyway
@@ -225,7 +227,11 @@ C2D_DEV uint32_t wave_count_hits(const Scene& sc, uint64_t seed, uint64_t scene_
                 hits += (uint32_t)__popcll(__ballot(sample_collides(sc, o) && in_range));
                 continue;
             }
+#ifdef C2D_MC_NO_PRETEST
+            const bool undecided = in_range;
+#else
             const bool undecided = in_range && !centre_pretest(sc, dx, dy);
+#endif
             const unsigned long long m = __ballot(undecided);
             if (m == 0ull) continue;  // the common case of a far scene: 64 certain misses
             if (m == ~0ull) dense = C2D_MC_PRETEST_HOLDOFF;
