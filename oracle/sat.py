@@ -140,3 +140,27 @@ def poly_collide_batch(vx, vy, k):
             sep = (mx[0] < mn[1]) | (mx[1] < mn[0])
             collide &= ~(sep & has_edge)
     return collide.astype(np.uint8)
+
+
+def _main():
+    """BASELINE config 1: the 1 000 fixed OBB pairs of tests/golden/sat_rect_1k.npz on the CPU,
+    boolean collide output.  `python oracle/sat.py [--print]`"""
+    import os
+    import sys
+    import time
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    g = np.load(os.path.join(here, "..", "tests", "golden", "sat_rect_1k.npz"))
+    planes = g["planes"]
+    t0 = time.perf_counter()
+    out = convex_collide(planes[:8].T, planes[8:].T)
+    dt = time.perf_counter() - t0
+    ok = np.array_equal(out, g["expected"])
+    if "--print" in sys.argv:
+        print("".join(str(int(v)) for v in out))
+    print(f"{len(out)} pairs, {int(out.sum())} colliding, {dt * 1e3:.2f} ms (numpy float32), matches the golden vector: {ok}")
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    raise SystemExit(_main())
