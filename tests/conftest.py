@@ -10,6 +10,22 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    _ensure_built()
+
+
+def _ensure_built():
+    """The suite needs lib/libc2d.so, the CLI drivers and the oracle: build whatever is missing
+    (a fresh checkout has none of them; hipcc cross-compiles gfx950 without a GPU)."""
+    import subprocess
+
+    pkg_dir = os.path.join(ROOT, "convex-2d-gpu-collision-detection_amd")
+    need = [os.path.join(pkg_dir, "lib", "libc2d.so"), os.path.join(ROOT, "oracle", "libc2d_oracle.so")]
+    need += [os.path.join(pkg_dir, "bin", b) for b in ("generate_dataset", "compute_collision_probability", "ztest")]
+    if all(os.path.exists(p) for p in need):
+        return
+    env = dict(os.environ)
+    env.setdefault("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.run(["make", "-C", ROOT, "-j4", "all"], check=True, env=env, stdout=subprocess.DEVNULL)
 
 
 @pytest.fixture(scope="session")
