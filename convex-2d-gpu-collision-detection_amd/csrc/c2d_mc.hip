@@ -15,6 +15,12 @@
 // memory, no set-up kernel, and any partition of the samples over waves, blocks
 // or GPUs gives the same hit count.  The kernel is VALU bound (~0 B of HBM
 // traffic per sample); see DESIGN.md for the per-sample op budget.
+//
+// Work avoidance that cannot change a result: a sample whose obstacle centre alone
+// proves a miss (bounding-disk argument, make_scene) is dropped after its first
+// Box-Muller pair, or — from the raw radius word — before any transcendental; the
+// undecided samples of a wave are compacted through an LDS queue so that the full
+// evaluation always runs on 64 busy lanes.
 #include "c2d_internal.hpp"
 #include "c2d_math.hpp"
 
