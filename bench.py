@@ -83,6 +83,8 @@ def main() -> None:
                     help="collective backend; nccl (= RCCL over xGMI) is the measured path, gloo only rehearses the N > 1 code "
                          "path on a box with fewer GPUs than ranks (together with --share-device)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: initialise the process group and run the collectives even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mc", action="store_true")
     ap.add_argument("--no-pose", action="store_true")
@@ -91,6 +93,13 @@ def main() -> None:
     ap.add_argument("--scenes-max-samples", type=int, default=120_000)
     ap.add_argument("--poly-pairs", type=int, default=10_000_000, help="config 5 polygon pairs per GPU; 0 = skip the leg")
     args = ap.parse_args()
+
+    # Exactly one line may reach stdout (the JSON result).  Libraries write there too — RCCL prints a
+    # version banner to stdout when its communicator is created — so fd 1 is pointed at stderr for the
+    # whole run and the result is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -116,8 +125,12 @@ def main() -> None:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -125,7 +138,7 @@ def main() -> None:
 
     def all_reduce_sum(t):
         """The one collective of each leg: sum of 64-bit counters over ranks, in place."""
-        if world == 1:
+        if not use_dist:
             return
         if args.backend == "nccl":
             with torch.cuda.stream(stream):
@@ -166,7 +179,7 @@ def main() -> None:
         eng.sat_rect_pairs_verts(plane_ptrs, n, out.data_ptr(), count.data_ptr(), stream=sh)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     def prewarm(fn):
@@ -387,9 +400,10 @@ def main() -> None:
             "roofline": roofline, "cpu_baseline": cpu_baseline, "pose_format": pose_leg, "mc": mc, "scenes": scenes_leg, "poly": poly_leg,
             "device": eng.info()["name"],
         }
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
