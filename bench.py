@@ -152,6 +152,14 @@ def main() -> None:
     eng = pkg.Engine(local_rank)  # raises if libc2d.so is missing or the device is not gfx950
     stream = torch.cuda.Stream(device=dev)
     sh = stream.cuda_stream
+    if use_dist:
+        # create the communicator now (RCCL does it lazily at the first collective and takes seconds):
+        # otherwise the first barrier in front of the timed region idles the GPU long enough for its
+        # clocks to drop, and the timed steps would run through the post-idle ramp
+        warm = torch.zeros(1, dtype=torch.int64, device=dev)
+        all_reduce_sum(warm)
+        dist.barrier()
+        torch.cuda.synchronize()
 
     # ---- workload: config 2, resident in HBM -----------------------------------------
     n = args.pairs
