@@ -74,7 +74,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--pairs", type=int, default=10_000_000, help="rectangle pairs per GPU (config 2: 1e7)")
     ap.add_argument("--mc-samples", type=int, default=100_000_000, help="MC samples per GPU (config 3: 1e8)")
-    ap.add_argument("--mc-reps", type=int, default=5)
+    ap.add_argument("--mc-reps", type=int, default=20)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target wall time of the CPU baseline leg")
     ap.add_argument("--prewarm-ms", type=float, default=150.0,
                     help="untimed device wake-up before the W warm-up steps: the first ~15 ms of load after idle run "
