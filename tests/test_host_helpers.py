@@ -1,0 +1,23 @@
+"""CPU test of the C++ host helpers (npy I/O, flag parser, driver_common) — compiles and runs
+tests/cpp/test_host_helpers.cpp, then cross-checks the .npy files it wrote with numpy."""
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_host_helpers(tmp_path):
+    exe = tmp_path / "test_host_helpers"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-I" + os.path.join(ROOT, "convex-2d-gpu-collision-detection_amd", "csrc", "host"),
+                    os.path.join(ROOT, "tests", "cpp", "test_host_helpers.cpp"), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe), str(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    a = np.load(tmp_path / "a1000.npy")
+    assert a.shape == (1000, 5) and a.dtype == np.float32 and a[3, 2] == np.float32(0.25 * 17 - 3.0)
+    assert np.load(tmp_path / "a0.npy").shape == (0, 5)
+    assert np.load(tmp_path / "one.npy").tolist() == [1.5, -2.5, 3.5]
+    # numpy's own histogram agrees with the edges used by the drivers' summary
+    cp = np.array([0.0, 0.0005, 0.001, 0.0099, 0.01, 0.05, 0.1, 0.5, 1.0], np.float32)
+    assert np.histogram(cp, [0, 0.001, 0.01, 0.1, 1])[0].tolist() == [2, 3, 1, 3]
