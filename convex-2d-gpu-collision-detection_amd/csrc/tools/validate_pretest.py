@@ -1,7 +1,7 @@
 """One-off soundness check of the Monte-Carlo pretests: hit counts of the shipped build vs a build that
 evaluates every sample in full (make lib-nopretest: -DC2D_MC_NO_PRETEST), on random scenes spread around
 the pretest boundary.  Developer tool, GPU only:  python validate_pretest.py <samples per scene> <scenes>
-Round 1: 400 scenes x 1e9 samples (p from 0 to 0.999, median 3.5e-4, 67 zero-hit scenes): identical."""
+Round 1: 2000 scenes x 1e9 samples (p from 0 to 1, median 6.6e-4, 365 zero-hit scenes): identical."""
 import sys, os, json, subprocess
 code = r'''
 import sys, os, json
