@@ -121,6 +121,28 @@ def test_mc_centre_pretest_boundary_sweep(eng, oracle):
     assert cases == 4 * 3 * 12
 
 
+@pytest.mark.parametrize("robot,pos,pose,sd", [
+    ((4.07, 1.74), (0.0, 0.0), (2.0, 1.0, 0.3), (0.0, 0.0, 0.0, 0.0, 0.0)),        # no noise at all, overlapping: p = 1
+    ((4.07, 1.74), (9.0, 0.0), (2.0, 1.0, 0.3), (0.0, 0.0, 0.0, 0.0, 0.0)),        # no noise, apart: p = 0
+    ((4.07, 1.74), (3.0, 0.5), (0.0, 0.0, 0.0), (0.3, 0.3, 0.2, 0.0, 0.0)),        # point obstacle
+    ((4.07, 1.74), (3.0, 0.5), (0.0, 3.0, 1.0), (0.3, 0.3, 0.8, 0.0, 0.0)),        # segment obstacle
+    ((0.0, 0.0), (0.5, 0.2), (2.0, 1.0, 0.0), (0.3, 0.3, 0.2, 0.0, 0.0)),          # point robot
+    ((4.07, 1.74), (3.0, 1.0), (2.0, 1.0, 0.6), (10.0, 10.0, 3.0, 0.0, 0.0)),      # huge noise
+    ((4.07, 1.74), (3.0, 1.0), (0.5, 0.5, 0.6), (0.3, 0.3, 0.2, 2.0, 2.0)),        # shape noise >> size: negative widths happen
+    ((4.07, 1.74), (1e4, -1e4), (2.0, 1.0, 0.6), (0.3, 0.3, 0.2, 0.0, 0.0)),       # robot very far: large coordinates
+    ((4.07, 1.74), (3.0, 1.0), (2.0, 1.0, 0.6), (1e-6, 1e-6, 1e-6, 0.0, 0.0)),     # almost no noise near the boundary
+    ((4.07, 1.74), (2.9, 0.0), (2.0, 1.0, 0.0), (0.0, 0.3, 0.0, 0.0, 0.0)),        # sigma_x = 0 only
+])
+def test_mc_pair_degenerate_scenes(eng, oracle, robot, pos, pose, sd):
+    """Degenerate sizes and noise levels: the pretest thresholds (rho = 0, G = 0, huge margins) must never
+    change a result."""
+    n = 60_000
+    d = eng.zeros(1, np.uint64)
+    eng.mc_pair(robot[0], robot[1], pos, pose, sd, 5, 9, 0, n, d)
+    assert int(d.get()[0]) == oracle.mc_pair(robot[0], robot[1], pos, pose, sd, 5, 9, 0, n)
+    d.free()
+
+
 def test_mc_pair_range_additivity_and_accumulation(eng, wl):
     """Disjoint sample ranges sum to the whole (this is what sharding over GPUs relies on),
     and d_hits accumulates across calls."""
