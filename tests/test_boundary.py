@@ -87,3 +87,12 @@ def test_stream_is_rocrand_philox(tmp_path, oracle):
         out = subprocess.run([str(exe), str(seed), str(scene), str(sample), "8"], check=True, capture_output=True, text=True).stdout
         ref = np.array([[int(v) for v in line.split()] for line in out.strip().splitlines()], np.uint32)
         assert np.array_equal(oracle.raw8(seed, scene, sample, 8), ref)
+
+
+def test_headers_are_plain_c(tmp_path):
+    """include/c2d.h and include/utils.h are the FFI surface: they must compile as C11 and as C++17."""
+    src = tmp_path / "t.c"
+    src.write_text('#include "c2d.h"\nint main(void){ float r[8]; create_rect(r, 2.f, 1.f); return sizeof(c2d_mc_scenes_args) > 0 ? 0 : 1; }\n')
+    inc = "-I" + os.path.join(ROOT, "include")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", inc, "-c", str(src), "-o", str(tmp_path / "t.o")], check=True)
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-pedantic", "-Werror", inc, "-x", "c++", "-c", str(src), "-o", str(tmp_path / "t2.o")], check=True)
