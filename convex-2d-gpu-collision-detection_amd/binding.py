@@ -76,6 +76,7 @@ _SIGNATURES = {
     "c2d_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "c2d_ctx_destroy": (C.c_int, [C.c_void_p]),
     "c2d_ctx_info": (C.c_int, [C.c_void_p, C.POINTER(_DeviceInfo)]),
+    "c2d_ctx_check_async": (C.c_int, [C.c_void_p]),
     "c2d_malloc": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]),
     "c2d_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "c2d_memset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
@@ -200,6 +201,10 @@ class Engine:
     def synchronize(self, stream: int = 0):
         self._check(self.lib.c2d_stream_synchronize(self.h, C.c_void_p(stream)), "c2d_stream_synchronize")
 
+    def check_async(self):
+        """Raise if a kernel of this ctx reported an argument error since the last check (c2d_ctx_check_async)."""
+        self._check(self.lib.c2d_ctx_check_async(self.h), "c2d_ctx_check_async")
+
     def stream_create(self) -> int:
         s = C.c_void_p()
         self._check(self.lib.c2d_stream_create(self.h, C.byref(s)), "c2d_stream_create")
@@ -299,6 +304,20 @@ class Engine:
                           C.pointer(total), C.pointer(iters))
         self._check(self.lib.c2d_mc_scenes(self.h, C.byref(a), C.c_void_p(stream)), "c2d_mc_scenes")
         return int(total.value), int(iters.value)
+
+    def mc_scenes_async(self, poses, num_poses, std_devs, num_std_devs, scenes, n_scenes, robot_w, robot_h, accuracy_bins,
+                        bin_accuracy, max_samples, seed, scene_id_base, hits, n_used, rows=None, stream: int = 0,
+                        schedule=(0, 0, 0)):
+        """c2d_mc_scenes without host outputs: the whole adaptive loop is only enqueued (no synchronisation)."""
+        bins = np.ascontiguousarray(accuracy_bins, dtype=np.float32)
+        acc = np.ascontiguousarray(bin_accuracy, dtype=np.float32)
+        if len(acc) != len(bins) - 1:
+            raise ValueError("bin_accuracy must have len(accuracy_bins) - 1 entries")
+        a = _McScenesArgs(_ptr_of(poses), num_poses, _ptr_of(std_devs), num_std_devs, _ptr_of(scenes), n_scenes, robot_w,
+                          robot_h, bins.ctypes.data_as(C.POINTER(C.c_float)), acc.ctypes.data_as(C.POINTER(C.c_float)),
+                          len(bins), max_samples, seed, scene_id_base, schedule[0], schedule[1], schedule[2],
+                          _ptr_of(hits), _ptr_of(n_used), _ptr_of(rows), None, None)
+        self._check(self.lib.c2d_mc_scenes(self.h, C.byref(a), C.c_void_p(stream)), "c2d_mc_scenes")
 
     def sample_scenes(self, poses, num_poses, std_devs, num_std_devs, robot_w, robot_h, spread, seed, scene_id_base,
                       n_scenes, scenes, stream: int = 0):

@@ -47,13 +47,19 @@ int c2d_ctx_create(int device, c2d_ctx** out)
     if (!g.ok) { delete ctx; return C2D_ERR_NO_DEVICE; }
     if (hipMalloc(&ctx->d_counters, 64) != hipSuccess || hipMalloc(&ctx->d_count_words, C2D_COUNT_WORDS_BYTES) != hipSuccess ||
         hipMemset(ctx->d_count_words, 0, C2D_COUNT_WORDS_BYTES) != hipSuccess || hipMalloc(&ctx->d_bins, 32 * sizeof(float)) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pinned), 64, hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pinned), 64, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&ctx->h_async_err), 64, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->d_async_err), ctx->h_async_err, 0) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ws_event, hipEventDisableTiming) != hipSuccess) {
         if (ctx->d_counters) (void)hipFree(ctx->d_counters);
         if (ctx->d_count_words) (void)hipFree(ctx->d_count_words);
         if (ctx->d_bins) (void)hipFree(ctx->d_bins);
+        if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+        if (ctx->h_async_err) (void)hipHostFree(ctx->h_async_err);
         delete ctx;
         return C2D_ERR_NOMEM;
     }
+    *ctx->h_async_err = 0;
     *out = ctx;
     return C2D_OK;
 }
@@ -68,6 +74,8 @@ int c2d_ctx_destroy(c2d_ctx* ctx)
     if (ctx->d_count_words) (void)hipFree(ctx->d_count_words);
     if (ctx->d_bins) (void)hipFree(ctx->d_bins);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->h_async_err) (void)hipHostFree(ctx->h_async_err);
+    if (ctx->ws_event) (void)hipEventDestroy(ctx->ws_event);
     delete ctx;
     return C2D_OK;
 }
@@ -158,7 +166,19 @@ int c2d_stream_synchronize(c2d_ctx* ctx, c2d_stream stream)
     if (!ctx) return C2D_ERR_INVALID_ARG;
     c2d::DeviceGuard g(ctx->device);
     C2D_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
-    return C2D_OK;
+    return c2d_ctx_check_async(ctx);
+}
+
+int c2d_ctx_check_async(c2d_ctx* ctx)
+{
+    if (!ctx) return C2D_ERR_INVALID_ARG;
+    const uint32_t e = __atomic_exchange_n(ctx->h_async_err, 0u, __ATOMIC_ACQ_REL);
+    if (e == 0) return C2D_OK;
+    if (e & C2D_ASYNC_ERR_POLY_K)
+        ctx->last_error = "c2d_sat_poly_pairs: vertex count outside 1..C2D_POLY_KMAX (reported asynchronously; those pairs were written as 0)";
+    else
+        ctx->last_error = "asynchronous argument error reported by a kernel";
+    return C2D_ERR_INVALID_ARG;
 }
 
 }  // extern "C"

@@ -19,8 +19,20 @@ struct c2d_ctx {
     unsigned long long* d_count_words = nullptr;  // 256 x 128 B arrival/sum words of the SAT count (self-clearing)
     float* d_bins = nullptr;                   // accuracy_bins | bin_accuracy (<= 32 floats)
     uint32_t* h_pinned = nullptr;              // pinned host word for count read-back
+    // Deferred argument errors found by kernels (e.g. a polygon vertex count outside 1..KMAX): a pinned,
+    // device-mapped word that kernels OR into with system scope; c2d_stream_synchronize /
+    // c2d_ctx_check_async read and clear it, so asynchronous entry points need no validation pass.
+    uint32_t* h_async_err = nullptr;
+    uint32_t* d_async_err = nullptr;           // device address of the same word
+    // Guard of the shared workspace (count words, adaptive state, survivor lists): the last call that used
+    // it recorded ws_event on ws_stream; a workspace call on another stream before that event completed is refused.
+    hipEvent_t ws_event = nullptr;
+    hipStream_t ws_stream = nullptr;
+    bool ws_busy = false;
     mutable std::string last_error;
 };
+
+#define C2D_ASYNC_ERR_POLY_K 1u   /* polygon vertex count outside 1..C2D_POLY_KMAX */
 
 #define C2D_COUNT_WORDS_BYTES (256 * 128)
 
@@ -68,6 +80,36 @@ struct DeviceGuard {
         if (prev >= 0) (void)hipSetDevice(prev);
     }
 };
+
+constexpr int kMaxGrid = 1 << 24;  // blocks per launch; kernels grid-stride beyond it
+
+// See c2d_ctx::ws_event.  Calls on ONE stream are ordered by the stream; the guard only refuses a call that would
+// run concurrently with an unfinished one on a different stream (C2D_ERR_UNSUPPORTED instead of silent corruption).
+inline int workspace_acquire(c2d_ctx* ctx, hipStream_t s, bool uses)
+{
+    if (!uses || !ctx->ws_busy || ctx->ws_stream == s) return C2D_OK;
+    if (hipEventQuery(ctx->ws_event) == hipErrorNotReady) {
+        ctx->last_error = "this c2d_ctx still has a call in flight on another stream (one workspace per ctx: use one ctx per stream)";
+        return C2D_ERR_UNSUPPORTED;
+    }
+    ctx->ws_busy = false;
+    return C2D_OK;
+}
+
+inline void workspace_release(c2d_ctx* ctx, hipStream_t s, bool uses)
+{
+    if (!uses) return;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        ctx->ws_busy = false;  // inside a graph capture: ordering of graph launches is the caller's business
+        return;
+    }
+    if (hipEventRecord(ctx->ws_event, s) == hipSuccess) {
+        ctx->ws_stream = s;
+        ctx->ws_busy = true;
+    }
+}
 
 inline int grid_for(size_t work_items, int block, int max_blocks)
 {

@@ -251,12 +251,20 @@ C2D_DEV uint32_t wave_count_hits(const Scene& sc, uint64_t seed, uint64_t scene_
         } else if (qn == 0) {
             break;
         }
-        // evaluate 64 queued samples (the last qn on the flush trip)
+        // evaluate 64 queued samples (the last qn on the flush trip).  Lanes read slots that other lanes of
+        // this wave wrote: LDS operations of a wave complete in order, the fence pair only stops the compiler
+        // from reordering the reads above the writes (no instruction is emitted)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const uint32_t take = qn < 64 ? qn : 64;
         const bool live = lane < take;
         const uint32_t src = qn - take + (live ? lane : 0);
         const float4 e = q.cw[src];
         const uint32_t eidx = q.idx[src];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // later queue writes stay behind these reads
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         qn -= take;
         float o[8];
         sample_obstacle(sc, __float_as_uint(e.z), __float_as_uint(e.w), e.x, e.y, seed, scene_id, begin + eidx, o);
@@ -673,6 +681,7 @@ int c2d_mc_scenes(c2d_ctx* ctx, const c2d_mc_scenes_args* a, c2d_stream stream)
 
     DeviceGuard g(ctx->device);
     hipStream_t s = (hipStream_t)stream;
+    if (int rc = workspace_acquire(ctx, s, true)) return rc;
     int st = ensure_lists(ctx, a->n_scenes);
     if (st != C2D_OK) return st;
     AdaptiveState* d_state = reinterpret_cast<AdaptiveState*>(ctx->d_counters);
@@ -709,6 +718,7 @@ int c2d_mc_scenes(c2d_ctx* ctx, const c2d_mc_scenes_args* a, c2d_stream stream)
         hipLaunchKernelGGL(mc_scenes_decide_kernel, dim3((unsigned)dec_blocks), dim3(256), 0, s, D);
     }
     C2D_LAUNCH_CHECK(ctx);
+    workspace_release(ctx, s, true);
     if (a->total_samples || a->iterations) {  // host outputs requested: one read-back at the end
         AdaptiveState* h_state = reinterpret_cast<AdaptiveState*>(ctx->h_pinned);
         C2D_HIP(ctx, hipMemcpyAsync(h_state, d_state, sizeof(AdaptiveState), hipMemcpyDeviceToHost, s));

@@ -1,0 +1,254 @@
+// c2d_poly.hip — SAT for arbitrary convex polygons, K <= 16 vertices, true edge normals
+// (BASELINE config 5; SURVEY.md F5: the reference's edge-as-axis shortcut, utils.cu:170-171,
+// is only valid for rectangles).  Projection and the strict-< interval test are
+// utils.cu:172-180 unchanged.
+//
+// The result is an OR over axes — "some axis separates" — so ANY axis that separates, evaluated
+// with exactly the canonical arithmetic, decides a pair; the order in which axes are tried is
+// free.  The kernel therefore runs in two phases per wave of 64 pairs:
+//
+//   phase 1, one pair per lane, everything in registers (no LDS, no cross-lane traffic):
+//     the 2 x 16 padded vertex rows arrive as coalesced 256-byte row segments (pair index is
+//     the fastest dimension), slots >= k are overwritten with vertex 0 (a repeated vertex adds
+//     a zero-length edge, whose axis (0, 0) never separates, and repeats a projection, which
+//     changes no min/max: padding is exactly neutral), and ONE axis of polygon A is tested: the
+//     edge whose normal is best aligned with the direction between the vertex means (a
+//     heuristic in fast arithmetic — it only chooses WHICH canonical axis is evaluated).
+//     On the bench workload (94 % of the pairs separated) this single axis decides 91 % of all
+//     pairs; rows above the wave's largest vertex count are neither loaded nor evaluated.
+//
+//   phase 2, the whole wave per undecided pair (colliding pairs need all (ka+kb)^2 products):
+//     the owner lane parks its 32 vertices in a 256-byte LDS slot; lane (axis a, half h)
+//     builds the normal of edge a (A's edges 0..15, B's 16..31) and projects polygon h's
+//     vertices onto it with two-vertex ds_read_b128 broadcasts; the two halves swap their
+//     intervals (lane ^ 32) and one ballot gives "some axis separates".
+//
+// The wave-wide early-out of the north star is this split: nothing beyond one axis is evaluated
+// for a pair that the first axis separates, and no lane idles on another pair's full evaluation.
+#include "c2d_internal.hpp"
+#include "c2d_math.hpp"
+#include "c2d_count.hpp"
+
+namespace c2d {
+
+constexpr int KM = C2D_POLY_KMAX;  // 16
+constexpr int kSlots = 8;          // undecided pairs parked in LDS per group (256 B each)
+
+C2D_DEV void minmax_update(float nx, float ny, float x, float y, float& mn, float& mx)
+{
+    const float p = nx * x + ny * y;  // unfused (translation unit is -ffp-contract=off), utils.cu:173
+    mn = __builtin_fminf(mn, p);
+    mx = __builtin_fmaxf(mx, p);
+}
+
+C2D_DEV uint32_t wave_max_u32(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
+        v = o > v ? o : v;
+    }
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+// One wave = one tile of 64 pairs.
+__global__ __launch_bounds__(64, 5) void sat_poly_kernel(const float* __restrict__ vx, const float* __restrict__ vy,
+                                                      const uint8_t* __restrict__ kcnt, size_t n,
+                                                      uint8_t* __restrict__ out,
+                                                      unsigned long long* __restrict__ d_count,
+                                                      unsigned long long* __restrict__ words,
+                                                      uint32_t* __restrict__ async_err)
+{
+    // phase-2 slots: A's 16 vertices then B's 16 vertices, (x, y) interleaved
+    __shared__ __attribute__((aligned(16))) float2 s_slot[kSlots][2 * KM];
+    const uint32_t lane = threadIdx.x;
+    uint32_t n_collide = 0;
+    const size_t n_tiles = (n + 63) / 64;
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t p0 = tile * 64;
+        const uint32_t here = (uint32_t)((n - p0) < (size_t)64 ? (n - p0) : (size_t)64);  // wave-uniform
+        const bool in = lane < here;
+        const uint32_t cl = in ? lane : here - 1;  // lanes past the end re-read the last pair (never stored)
+        // ---- vertex counts; out-of-range counts are clamped (memory safety) and reported -------
+        int ka = kcnt[p0 + cl], kb = kcnt[n + p0 + cl];
+        const bool bad = ka < 1 || ka > KM || kb < 1 || kb > KM;
+        ka = ka < 1 ? 1 : (ka > KM ? KM : ka);
+        kb = kb < 1 ? 1 : (kb > KM ? KM : kb);
+        if (__ballot(bad) != 0 && lane == 0) __hip_atomic_fetch_or(async_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const int kmaxA = (int)wave_max_u32((uint32_t)ka), kmaxB = (int)wave_max_u32((uint32_t)kb);
+        // ---- rows: scalar base + 32-bit lane offset, rows >= the wave's maximum are skipped ------
+        float ax[KM], ay[KM], bx[KM], by[KM];
+        const float* rx = vx + p0;
+        const float* ry = vy + p0;
+        // byte offset of the lane: global_load_dword v, v_off, s[base] (scalar row base + zero-extended 32-bit
+        // lane offset) costs no address arithmetic.  The empty asm keeps the zero-extension next to each load:
+        // hoisted out of the row's block, instruction selection no longer sees it and falls back to a 64-bit add.
+        uint32_t off = cl * 4u;
+        auto ld = [&off](const float* row) {
+            asm volatile("" : "+v"(off));
+            return __builtin_nontemporal_load(reinterpret_cast<const float*>(reinterpret_cast<const char*>(row) + off));
+        };
+#pragma unroll
+        for (int r = 0; r < KM; r++) {
+            if (r < kmaxA) {
+                ax[r] = ld(rx);
+                ay[r] = ld(ry);
+            } else {
+                ax[r] = 0.0f;
+                ay[r] = 0.0f;
+            }
+            rx += n;
+            ry += n;
+        }
+#pragma unroll
+        for (int r = 0; r < KM; r++) {
+            if (r < kmaxB) {
+                bx[r] = ld(rx);
+                by[r] = ld(ry);
+            } else {
+                bx[r] = 0.0f;
+                by[r] = 0.0f;
+            }
+            rx += n;
+            ry += n;
+        }
+        // ---- neutral padding: slots >= k repeat vertex 0; vertex sums for the heuristic -------------
+        float sax = ax[0], say = ay[0], sbx = bx[0], sby = by[0];
+#pragma unroll
+        for (int r = 1; r < KM; r++) {
+            const bool ua = r < ka, ub = r < kb;
+            ax[r] = ua ? ax[r] : ax[0];
+            ay[r] = ua ? ay[r] : ay[0];
+            bx[r] = ub ? bx[r] : bx[0];
+            by[r] = ub ? by[r] : by[0];
+            if (r < kmaxA) { sax += ax[r]; say += ay[r]; }
+            if (r < kmaxB) { sbx += bx[r]; sby += by[r]; }
+        }
+        // mean of the real vertices: the sums above hold (kmax - k) extra copies of vertex 0
+        const float fka = (float)ka, fkb = (float)kb;
+        const float ia = __builtin_amdgcn_rcpf(fka), ib = __builtin_amdgcn_rcpf(fkb);
+        float dX = (sbx - (float)(kmaxB - kb) * bx[0]) * ib - (sax - (float)(kmaxA - ka) * ax[0]) * ia;
+        float dY = (sby - (float)(kmaxB - kb) * by[0]) * ib - (say - (float)(kmaxA - ka) * ay[0]) * ia;
+        // orientation of A (sign of the first corner's cross product): clockwise polygons have
+        // inward-pointing (-ey, ex), so the preferred direction flips
+        {
+            const float c = (ax[1] - ax[0]) * (ay[2] - ay[0]) - (ay[1] - ay[0]) * (ax[2] - ax[0]);
+            const uint32_t sgn = __float_as_uint(c) & 0x80000000u;
+            dX = __uint_as_float(__float_as_uint(dX) ^ sgn);
+            dY = __uint_as_float(__float_as_uint(dY) ^ sgn);
+        }
+        // ---- phase 1: pick A's edge whose normal points best towards B, test that one axis -----------
+        float best = -__builtin_inff(), nx1 = 0.0f, ny1 = 0.0f;
+#pragma unroll
+        for (int r = 0; r < KM; r++) {
+            if (r < kmaxA) {
+                const int r1 = (r + 1) & (KM - 1);
+                const float ey = ay[r1] - ay[r];
+                const float nx = -ey;               // true normal (-ey, ex), exactly as phase 2 and the oracle
+                const float ny = ax[r1] - ax[r];
+                const float nd = fma_(nx, dX, ny * dY);
+                const float l2 = fma_(nx, nx, ny * ny);
+                const float s = nd * __builtin_amdgcn_rsqf(l2);  // zero edge: 0 * inf = NaN, never "better"
+                const bool better = s > best;
+                best = better ? s : best;
+                nx1 = better ? nx : nx1;
+                ny1 = better ? ny : ny1;
+            }
+        }
+        float mnA = __builtin_inff(), mxA = -__builtin_inff(), mnB = __builtin_inff(), mxB = -__builtin_inff();
+#pragma unroll
+        for (int r = 0; r < KM; r++)
+            if (r < kmaxA) minmax_update(nx1, ny1, ax[r], ay[r], mnA, mxA);
+#pragma unroll
+        for (int r = 0; r < KM; r++)
+            if (r < kmaxB) minmax_update(nx1, ny1, bx[r], by[r], mnB, mxB);
+        bool sep = (mxA < mnB) || (mxB < mnA);
+        sep = sep || bad;  // out-of-range vertex count: reported, result 0
+        // ---- phase 2: full evaluation of the pairs that are still undecided -------------------------------
+        // Up to kSlots undecided lanes park their vertices at once (the 16 ds_write_b128 are issued once per
+        // group, not once per pair); then each HALF-wave evaluates one parked pair: lane a of the half owns
+        // axis slot a (A's edges 0..15, B's edges 16..31) and projects all vertices of both polygons, two per
+        // broadcast ds_read_b128, so "some axis separates" is one ballot half and no lane exchange is needed.
+        unsigned long long todo = __ballot(in && !sep);
+        const int a = (int)(lane & 31u);
+        const int half = (int)(lane >> 5);
+        const int i0 = a, i1 = (a & KM) | ((a + 1) & (KM - 1));
+        while (todo) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u));
+            const bool park = ((todo >> lane) & 1ull) && rank < (uint32_t)kSlots;
+            __syncthreads();  // single-wave block: a wave-level fence (no s_barrier is emitted); earlier reads are done
+            if (park) {
+                float4* S4 = reinterpret_cast<float4*>(&s_slot[rank][0]);
+#pragma unroll
+                for (int r = 0; r < KM / 2; r++) {
+                    S4[r] = make_float4(ax[2 * r], ay[2 * r], ax[2 * r + 1], ay[2 * r + 1]);
+                    S4[KM / 2 + r] = make_float4(bx[2 * r], by[2 * r], bx[2 * r + 1], by[2 * r + 1]);
+                }
+            }
+            __syncthreads();
+            const int left = __popcll(todo);
+            const int g = left < kSlots ? left : kSlots;
+            for (int i = 0; i < g; i += 2) {
+                const int j0 = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const bool two = i + 1 < g;
+                const int j1 = two ? __ffsll((long long)todo) - 1 : j0;
+                if (two) todo &= todo - 1;
+                const int kA0 = __builtin_amdgcn_readlane(ka, j0), kA1 = __builtin_amdgcn_readlane(ka, j1);
+                const int kB0 = __builtin_amdgcn_readlane(kb, j0), kB1 = __builtin_amdgcn_readlane(kb, j1);
+                const int kA = kA0 > kA1 ? kA0 : kA1, kB = kB0 > kB1 ? kB0 : kB1;  // wave-uniform loop bounds
+                const float2* S = &s_slot[i + (two ? half : 0)][0];  // a lone last pair is evaluated by both halves
+                const float4* S4 = reinterpret_cast<const float4*>(S);
+                const float2 e0 = S[i0], e1 = S[i1];
+                const float nx = -(e1.y - e0.y), ny = e1.x - e0.x;
+                float mn1 = __builtin_inff(), mx1 = -__builtin_inff(), mn2 = __builtin_inff(), mx2 = -__builtin_inff();
+                // slots past a polygon's count repeat its vertex 0, so running to the larger count of the two
+                // pairs (rounded up to a vertex pair) needs no masking; one read ahead hides the LDS latency
+                float4 q = S4[0];
+                for (int r2 = 0; 2 * r2 < kA; r2++) {
+                    const float4 qn = S4[r2 + 1];  // r2 + 1 <= 8: at worst B's first pair, always inside the slot
+                    minmax_update(nx, ny, q.x, q.y, mn1, mx1);
+                    minmax_update(nx, ny, q.z, q.w, mn1, mx1);
+                    q = qn;
+                }
+                q = S4[KM / 2];
+                for (int r2 = 0; 2 * r2 < kB; r2++) {
+                    const float4 qn = S4[KM / 2 + ((r2 + 1) & (KM / 2 - 1))];
+                    minmax_update(nx, ny, q.x, q.y, mn2, mx2);
+                    minmax_update(nx, ny, q.z, q.w, mn2, mx2);
+                    q = qn;
+                }
+                const unsigned long long bal = __ballot((mx1 < mn2) || (mx2 < mn1));
+                const bool any0 = (uint32_t)bal != 0u, any1 = (uint32_t)(bal >> 32) != 0u;
+                sep = ((int)lane == j0) ? any0 : sep;
+                sep = (two && (int)lane == j1) ? any1 : sep;
+            }
+        }
+        const bool collide = in && !sep;
+        if (in) out[p0 + lane] = collide ? (uint8_t)1 : (uint8_t)0;
+        n_collide += (uint32_t)__popcll(__ballot(collide));
+    }
+    if (d_count) wave_count_arrive_total(n_collide, d_count, words);
+}
+
+}  // namespace c2d
+
+using namespace c2d;
+
+extern "C" int c2d_sat_poly_pairs(c2d_ctx* ctx, const float* d_vx, const float* d_vy, const uint8_t* d_k, size_t n,
+                                  uint8_t* d_out, unsigned long long* d_count, c2d_stream stream)
+{
+    if (!ctx) return C2D_ERR_INVALID_ARG;
+    if (n == 0) return C2D_OK;
+    if (!d_vx || !d_vy || !d_k || !d_out) return fail_arg(ctx, "c2d_sat_poly_pairs: NULL argument");
+    DeviceGuard g(ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    if (int rc = workspace_acquire(ctx, s, d_count != nullptr)) return rc;
+    const size_t n_tiles = (n + 63) / 64;
+    const int grid = (int)(n_tiles < (size_t)kMaxGrid ? n_tiles : (size_t)kMaxGrid);
+    hipLaunchKernelGGL(sat_poly_kernel, dim3(grid), dim3(64), 0, s, d_vx, d_vy, d_k, n, d_out, d_count, ctx->d_count_words,
+                       ctx->d_async_err);
+    C2D_LAUNCH_CHECK(ctx);
+    workspace_release(ctx, s, d_count != nullptr);
+    return C2D_OK;
+}

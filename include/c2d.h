@@ -15,8 +15,10 @@
  *   - work is enqueued on the caller's stream (a hipStream_t passed as void*,
  *     NULL = the default stream) and is asynchronous unless stated otherwise;
  *   - a c2d_ctx is bound to one device and owns a small device workspace (partial
- *     counts, adaptive-loop lists): use one ctx per device and per host thread, and
- *     do not run two calls of the same ctx concurrently on different streams.
+ *     counts, adaptive-loop lists): use one ctx per device and per host thread.  Calls
+ *     that use the workspace (c2d_mc_scenes; the SAT entry points when d_count != NULL)
+ *     are ordered by their stream; issuing one on stream B while an earlier one on
+ *     stream A has not finished returns C2D_ERR_UNSUPPORTED (use one ctx per stream).
  *
  * Arithmetic contract (DESIGN.md §"Canonical arithmetic"): IEEE binary32,
  * round-to-nearest-even, no multiply-add contraction except where the spec
@@ -78,6 +80,12 @@ int c2d_device_count(int* count);
 int c2d_ctx_create(int device, c2d_ctx** out);
 int c2d_ctx_destroy(c2d_ctx* ctx);
 int c2d_ctx_info(const c2d_ctx* ctx, c2d_device_info* out);
+/* Argument errors that only the device can see (today: a polygon vertex count outside
+ * 1..C2D_POLY_KMAX) are reported asynchronously: the kernel records them in a pinned word
+ * of the ctx and the first c2d_stream_synchronize — or this call, for callers that
+ * synchronise by other means — after the kernel finished returns C2D_ERR_INVALID_ARG once
+ * (c2d_last_error() says what) and clears the record.  Returns C2D_OK if nothing is pending. */
+int c2d_ctx_check_async(c2d_ctx* ctx);
 
 /* ---- memory / stream plumbing ---------------------------------------------
  * Replace cudaMalloc / cudaMemcpy / cudaFree / cudaDeviceSynchronize in the
@@ -144,7 +152,11 @@ int c2d_sat_rect_pairs_pose(c2d_ctx* ctx, const float* const d_pose_planes[10], 
  * rectangles.
  *   d_vx, d_vy : f32[2][C2D_POLY_KMAX][n]   (polygon, vertex, pair) — pair index fastest
  *   d_k        : u8[2][n]                    vertex counts, 1..C2D_POLY_KMAX
- *   d_out      : u8[n] */
+ *   d_out      : u8[n]
+ * Padded vertex slots (index >= count) are never interpreted.  The call is asynchronous
+ * and graph-capturable; vertex counts are checked on the device: a pair with a count
+ * outside 1..C2D_POLY_KMAX gets result 0 and the error is reported by the next
+ * c2d_stream_synchronize / c2d_ctx_check_async (see there). */
 int c2d_sat_poly_pairs(c2d_ctx* ctx, const float* d_vx, const float* d_vy, const uint8_t* d_k,
                        size_t n, uint8_t* d_out, unsigned long long* d_count, c2d_stream stream);
 

@@ -59,6 +59,14 @@ def main():
                                   acc.ctypes.data_as(C.POINTER(C.c_float)), 4, 2000, 5, 0, 0, 0, 0, d_h.ptr, d_u.ptr, None, None, None)
         assert lib.c2d_mc_scenes(eng.h, C.byref(a), C.c_void_p(stream)) == 0
 
+    # polygons (config 5 entry point): validation happens inside the kernel, so the call is capturable
+    npoly = 20_000
+    pvx_h, pvy_h, pk_h = wl.random_convex_polygons(npoly, seed=77, extent=3.0)
+    pvx, pvy, pk = (torch.from_numpy(x).to(dev) for x in (pvx_h, pvy_h, pk_h))
+    pout = torch.zeros(npoly, dtype=torch.uint8, device=dev)
+    pcnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    pose_out = torch.zeros(n, dtype=torch.uint8, device=dev)
+
     g = torch.cuda.CUDAGraph()
     side = torch.cuda.Stream(device=dev)
     with torch.cuda.graph(g, stream=side):
@@ -68,6 +76,8 @@ def main():
         eng.sat_rect_pairs_verts([row(planes, k) for k in range(16)], n, out.data_ptr(), cnt.data_ptr(), stream=sh)
         eng.mc_pair(sc["robot_w"], sc["robot_h"], sc["pos"], sc["pose"], sc["std_dev"], 1, 2, 3, 100_000, hits.data_ptr(), stream=sh)
         mc_scenes_async(sh)
+        eng.sat_poly_pairs(pvx.data_ptr(), pvy.data_ptr(), pk.data_ptr(), npoly, pout.data_ptr(), pcnt.data_ptr(), stream=sh)
+        eng.sat_rect_pairs_pose([row(pose, k) for k in range(10)], n, pose_out.data_ptr(), None, stream=sh)
     torch.cuda.synchronize()
     assert int(cnt.item()) == 0 and not out.any(), "capture must not execute anything"
     for _ in range(3):
@@ -81,6 +91,10 @@ def main():
     ref_hits = oracle.mc_pair(sc["robot_w"], sc["robot_h"], sc["pos"], sc["pose"], sc["std_dev"], 1, 2, 3, 100_000)
     assert int(hits.item()) == 3 * ref_hits
     assert np.array_equal(d_h.get(), ref_h) and np.array_equal(d_u.get(), ref_u)   # scenes re-zero their counters per call
+    ref_poly, ref_pcnt = oracle.sat_poly_pairs(pvx_h, pvy_h, pk_h)
+    assert np.array_equal(pout.cpu().numpy(), ref_poly) and int(pcnt.item()) == 3 * ref_pcnt
+    assert np.array_equal(pose_out.cpu().numpy(), ref_out)
+    eng.check_async()
 
 
 if __name__ == "__main__":

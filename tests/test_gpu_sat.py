@@ -216,11 +216,97 @@ def test_poly_random(eng, oracle, wl, n, kmin, kmax):
     assert np.array_equal(out, ref) and cnt == ref_cnt
 
 
-def test_poly_bad_vertex_count_is_an_error(eng, pkg, wl):
+@pytest.mark.parametrize("n,kmin,kmax,extent", [(63, 3, 16, 1.0), (64, 3, 16, 1.0), (129, 1, 16, 0.5), (5000, 3, 16, 0.7),
+                                                 (100_003, 3, 16, 1.5), (30_000, 3, 4, 1.0), (30_000, 12, 16, 1.0)])
+def test_poly_dense_scenes(eng, oracle, wl, n, kmin, kmax, extent):
+    """Small extents: most pairs collide or nearly touch, so the wave-cooperative full evaluation
+    (phase 2 of sat_poly_kernel) decides most of them."""
+    vx, vy, k = wl.random_convex_polygons(n, seed=1000 + n, kmin=kmin, kmax=kmax, extent=extent)
+    ref, ref_cnt = oracle.sat_poly_pairs(vx, vy, k)
+    out, cnt = run_poly(eng, vx, vy, k)
+    assert np.array_equal(out, ref) and cnt == ref_cnt
+    assert 0.2 < ref.mean() < 1.0
+
+
+def test_poly_padding_is_never_interpreted_and_orientation_is_free(eng, oracle, wl):
+    """Slots at and beyond the vertex count may hold anything (NaN, inf, huge values); clockwise polygons
+    (inward-pointing (-ey, ex)) must give the oracle's booleans as well."""
+    n = 40_000
+    vx, vy, k = wl.random_convex_polygons(n, seed=5, extent=2.0)
+    ref, ref_cnt = oracle.sat_poly_pairs(vx, vy, k)
+    junk = np.array([np.nan, np.inf, -np.inf, 3e38, -1e-40], np.float32)
+    rng = np.random.default_rng(3)
+    for p in range(2):
+        mask = np.arange(wl.KMAX)[:, None] >= k[p][None, :]
+        vx[p][mask] = rng.choice(junk, size=int(mask.sum()))
+        vy[p][mask] = rng.choice(junk, size=int(mask.sum()))
+    out, cnt = run_poly(eng, vx, vy, k)
+    assert np.array_equal(out, ref) and cnt == ref_cnt
+    # reverse the vertex order of every second polygon A and every third polygon B
+    cw_x, cw_y = vx.copy(), vy.copy()
+    for p, step in ((0, 2), (1, 3)):
+        for kk in range(1, wl.KMAX + 1):
+            sel = np.flatnonzero((k[p] == kk) & (np.arange(n) % step == 0))
+            cw_x[p][:kk, sel] = vx[p][:kk, sel][::-1]
+            cw_y[p][:kk, sel] = vy[p][:kk, sel][::-1]
+    ref2, ref2_cnt = oracle.sat_poly_pairs(np.nan_to_num(cw_x, nan=0, posinf=0, neginf=0), np.nan_to_num(cw_y, nan=0, posinf=0, neginf=0), k)
+    out2, cnt2 = run_poly(eng, cw_x, cw_y, k)
+    assert np.array_equal(out2, ref2) and cnt2 == ref2_cnt
+
+
+def test_poly_bad_vertex_count_is_reported_at_the_next_sync(eng, pkg, wl):
+    """Vertex counts are checked inside the kernel (the call stays asynchronous and capturable): the pair is
+    written as 0 and the error comes back from the next c2d_stream_synchronize / c2d_ctx_check_async, once."""
     vx, vy, k = wl.random_convex_polygons(100, seed=1)
-    k[1, 37] = 17
+    for bad in (17, 0, 255):
+        k2 = k.copy()
+        k2[1, 37] = bad
+        with pytest.raises(pkg.C2DError) as ei:
+            run_poly(eng, vx, vy, k2)
+        assert ei.value.status == -1 and "vertex count" in str(ei.value)
+        eng.check_async()  # reported once, then clear
+    # the other pairs of such a batch are still evaluated; the bad one reads 0
+    k2 = k.copy()
+    k2[0, 5] = 200
+    dvx, dvy, dk = eng.to_device(vx), eng.to_device(vy), eng.to_device(k2)
+    d_out = eng.zeros(100, np.uint8)
+    eng.sat_poly_pairs(dvx, dvy, dk, 100, d_out, None)
     with pytest.raises(pkg.C2DError):
-        run_poly(eng, vx, vy, k)
-    k[1, 37] = 0
-    with pytest.raises(pkg.C2DError):
-        run_poly(eng, vx, vy, k)
+        eng.synchronize()
+    got = d_out.get()
+    from oracle import cpu as oracle
+
+    ref, _ = oracle.sat_poly_pairs(vx, vy, k)
+    ref[5] = 0
+    assert np.array_equal(got, ref)
+    for a in (dvx, dvy, dk, d_out):
+        a.free()
+
+
+def test_workspace_guard_refuses_a_second_stream(eng, pkg, wl):
+    """The ctx owns one workspace: a counting call on stream B while a call on stream A is still running
+    returns C2D_ERR_UNSUPPORTED instead of corrupting both (include/c2d.h conventions)."""
+    tp, ts, _ = wl.random_tables(64, 64, seed=2)
+    d_p, d_s = eng.to_device(tp), eng.to_device(ts)
+    ns = 200_000
+    d_sc = eng.empty(ns, pkg.SCENE_DT)
+    eng.sample_scenes(d_p, 64, d_s, 64, 4.07, 1.74, 4.0, 1, 0, ns, d_sc)
+    d_h, d_u = eng.zeros(ns, np.uint32), eng.zeros(ns, np.uint32)
+    planes = eng.to_device(np.zeros((16, 256), np.float32))
+    d_out, d_cnt = eng.zeros(256, np.uint8), eng.zeros(1, np.uint64)
+    eng.synchronize()
+    sa, sb = eng.stream_create(), eng.stream_create()
+    eng.mc_scenes_async(d_p, 64, d_s, 64, d_sc, ns, 4.07, 1.74, wl.DEFAULT_BINS, wl.DEFAULT_BIN_ACCURACY, 400_000, 3, 0, d_h, d_u,
+                        stream=sa)  # tens of milliseconds of queued work
+    with pytest.raises(pkg.C2DError) as ei:
+        eng.sat_rect_pairs_verts([planes.row(i) for i in range(16)], 256, d_out, d_cnt, stream=sb)
+    assert ei.value.status == -5
+    eng.sat_rect_pairs_verts([planes.row(i) for i in range(16)], 256, d_out, None, stream=sb)  # no count: no workspace
+    eng.synchronize(sa)
+    eng.sat_rect_pairs_verts([planes.row(i) for i in range(16)], 256, d_out, d_cnt, stream=sb)  # stream A is done
+    eng.synchronize(sb)
+    assert int(d_cnt.get()[0]) == 256
+    eng.stream_destroy(sa)
+    eng.stream_destroy(sb)
+    for a in (d_p, d_s, d_sc, d_h, d_u, planes, d_out, d_cnt):
+        a.free()
