@@ -7,7 +7,7 @@ HIPCC    ?= /opt/rocm/bin/hipcc
 # -fno-slp-vectorize: hipcc otherwise packs scalar f32 ops into v_pk_mul/add_f32, measured 2 % slower here.
 HIPFLAGS := -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fPIC -Wall -Wextra -Wno-unused-parameter -Iinclude
 
-SRCS := $(CSRC)/c2d_api.hip $(CSRC)/c2d_sat.hip $(CSRC)/c2d_poly.hip $(CSRC)/c2d_mc.hip
+SRCS := $(CSRC)/c2d_api.hip $(CSRC)/c2d_sat.hip $(CSRC)/c2d_poly.hip $(CSRC)/c2d_mc.hip $(CSRC)/c2d_dist.hip
 OBJS := $(SRCS:.hip=.o)
 HDRS := $(CSRC)/c2d_math.hpp $(CSRC)/c2d_count.hpp $(CSRC)/c2d_internal.hpp include/c2d.h include/utils.h
 
@@ -20,7 +20,7 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 
 $(LIBDIR)/libc2d.so: $(OBJS)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(OBJS)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(OBJS) -ldl
 
 oracle:
 	$(MAKE) -C oracle
@@ -49,4 +49,4 @@ $(CSRC)/tools/%: $(CSRC)/tools/%.hip $(HDRS)
 # validation build: Monte-Carlo kernels without the certain-miss pretests (tools/validate_pretest.py)
 lib-nopretest: $(LIBDIR)/libc2d.so
 	$(HIPCC) $(HIPFLAGS) -DC2D_MC_NO_PRETEST -c $(CSRC)/c2d_mc.hip -o $(CSRC)/c2d_mc_nopretest.o
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $(LIBDIR)/libc2d_nopretest.so $(CSRC)/c2d_api.o $(CSRC)/c2d_sat.o $(CSRC)/c2d_poly.o $(CSRC)/c2d_mc_nopretest.o
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $(LIBDIR)/libc2d_nopretest.so $(CSRC)/c2d_api.o $(CSRC)/c2d_sat.o $(CSRC)/c2d_poly.o $(CSRC)/c2d_dist.o $(CSRC)/c2d_mc_nopretest.o -ldl

@@ -16,8 +16,16 @@ The same JSON line also carries
                  samples per GPU, sample ranges sharded over ranks, one all-reduce
                  of the hit count), with its VALU-roofline note.
 
-Launch: `python bench.py [--gpus N --steps K --warmup W]`; for N > 1 under
-`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`.
+Launch: `python bench.py [--gpus N --steps K --warmup W]`.  With N > 1 and no launcher
+environment (RANK / WORLD_SIZE unset) the process starts the N ranks itself — before it
+imports torch or touches a GPU — as children of `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 ...`, relays rank 0's JSON line and exits with
+the children's status; launched under torch.distributed.run directly it is one of the ranks.
+
+The reduce of each leg is the product's own: c2d_dist_all_reduce_sum_u64 of libc2d.so
+(ncclAllReduce of RCCL over xGMI, include/c2d.h); torch.distributed provides rendezvous,
+barriers and the max-over-ranks of the timings.  If the c2d communicator cannot be created the
+bench falls back to torch.distributed's all_reduce and says so in `config.reduce`.
 """
 from __future__ import annotations
 
@@ -35,9 +43,46 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_PAIR = 65            # 16 planes x 4 B read + 1 B written
 FP32_VALU_PEAK_TFLOPS = 157.3  # spec, FMA counted as 2
-VALU_INSTR_PER_SAMPLE = 343    # config-3 scene: SQ_INSTS_VALU x 64 / samples (profiles/r01e_pmc_sq.txt); a fully
-                               # evaluated sample costs 432, one ruled out by its centre alone about 105
+VALU_PEAK_TLANE = FP32_VALU_PEAK_TFLOPS / 2  # 10^12 VALU lane-instructions/s (one FMA lane = 2 flop)
 KMAX = 16
+
+
+def measured_counts():
+    """PMC-measured per-unit instruction counts and traffic of the current kernels on the bench workloads
+    (profiles/measured_counts.json, written from the rocprofv3 --pmc passes named in its `source` fields).
+    They are properties of (kernel build, workload): a leg whose workload differs from the recorded one
+    gets no VALU roofline instead of a wrong one."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "measured_counts.json")))
+    except Exception:
+        return {}
+
+
+def self_launch(n_gpus: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh processes.  This parent has not
+    imported torch and never touches a GPU; it relays rank 0's JSON line and the children's exit status."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in proc.stdout.splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if line is not None:
+        print(line, flush=True)
+    if proc.returncode != 0:
+        return proc.returncode
+    return 0 if line is not None else 1
 
 
 def torch_random_convex_polygons(torch, dev, n, seed, kmin=3, kmax=KMAX, extent=8.0):
@@ -80,11 +125,14 @@ def main() -> None:
                     help="untimed device wake-up before the W warm-up steps: the first ~15 ms of load after idle run "
                          "up to 12 %% slower while the power manager ramps clocks (profiles/r01a trace)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="collective backend; nccl (= RCCL over xGMI) is the measured path, gloo only rehearses the N > 1 code "
-                         "path on a box with fewer GPUs than ranks (together with --share-device)")
+                    help="torch.distributed backend for rendezvous / barriers; nccl (= RCCL over xGMI) is the measured path, gloo only "
+                         "rehearses the N > 1 code path on a box with fewer GPUs than ranks (together with --share-device; the "
+                         "c2d reduce then uses its file rehearsal transport, since RCCL refuses two ranks on one device)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: initialise the process group and run the collectives even with one rank")
+    ap.add_argument("--reduce", default="c2d", choices=["c2d", "torch"],
+                    help="who sums the hit counters over ranks: libc2d's c2d_dist (RCCL, default) or torch.distributed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mc", action="store_true")
     ap.add_argument("--no-pose", action="store_true")
@@ -92,7 +140,12 @@ def main() -> None:
                     help="config 4 data points per GPU (1e6 scenes x 32 obstacle instances / 8 GPUs); 0 = skip the leg")
     ap.add_argument("--scenes-max-samples", type=int, default=120_000)
     ap.add_argument("--poly-pairs", type=int, default=10_000_000, help="config 5 polygon pairs per GPU; 0 = skip the leg")
+    ap.add_argument("--poly-reps", type=int, default=20)
     args = ap.parse_args()
+
+    launched = "WORLD_SIZE" in os.environ or "RANK" in os.environ
+    if args.gpus > 1 and not launched:
+        sys.exit(self_launch(args.gpus))  # nothing GPU-related has been imported yet
 
     # Exactly one line may reach stdout (the JSON result).  Libraries write there too — RCCL prints a
     # version banner to stdout when its communicator is created — so fd 1 is pointed at stderr for the
@@ -115,10 +168,7 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     if args.share_device:
@@ -135,12 +185,50 @@ def main() -> None:
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+            os.environ["C2D_DIST_TRANSPORT"] = "file"  # rehearsal: RCCL cannot put two ranks on one device
+
+    eng = pkg.Engine(local_rank)  # raises if libc2d.so is missing or the device is not gfx950
+    stream = torch.cuda.Stream(device=dev)
+    sh = stream.cuda_stream
+    counts = measured_counts()
+
+    # ---- the reduce: libc2d's communicator (RCCL), created now — RCCL takes seconds for that, and an idle GPU in
+    # front of the timed region would run its first steps through the post-idle clock ramp
+    cdist, reduce_impl = None, "none (single rank)"
+    if use_dist:
+        reduce_impl = "torch.distributed all_reduce (%s)" % args.backend
+        if args.reduce == "c2d":
+            ok = 1
+            try:
+                if args.backend == "nccl":
+                    id_t = torch.zeros(pkg.binding.DIST_ID_BYTES, dtype=torch.uint8, device=dev)
+                    if rank == 0:
+                        id_t.copy_(torch.frombuffer(bytearray(eng.dist_unique_id()), dtype=torch.uint8))
+                    dist.broadcast(id_t, 0)
+                    uid = bytes(id_t.cpu().numpy().tobytes())
+                else:
+                    box = [eng.dist_unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(box, 0)
+                    uid = box[0]
+                cdist = eng.dist_init(rank, world, uid)
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] rank {rank}: c2d_dist unavailable ({e}); falling back to torch.distributed", file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev if args.backend == "nccl" else None)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                reduce_impl = "libc2d c2d_dist_all_reduce_sum_u64 (%s, %d ranks in the communicator)" % (cdist.transport, cdist.world_size)
+            elif cdist is not None:
+                cdist.close()
+                cdist = None
 
     def all_reduce_sum(t):
-        """The one collective of each leg: sum of 64-bit counters over ranks, in place."""
+        """The one collective of each leg: sum of 64-bit counters over ranks, in place (t: int64 device tensor)."""
         if not use_dist:
             return
-        if args.backend == "nccl":
+        if cdist is not None:
+            cdist.all_reduce_sum_u64(t.data_ptr(), t.numel(), stream=sh)
+        elif args.backend == "nccl":
             with torch.cuda.stream(stream):
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)
         else:  # rehearsal backend: reduce a host copy
@@ -149,13 +237,7 @@ def main() -> None:
             dist.all_reduce(h, op=dist.ReduceOp.SUM)
             t.copy_(h)
 
-    eng = pkg.Engine(local_rank)  # raises if libc2d.so is missing or the device is not gfx950
-    stream = torch.cuda.Stream(device=dev)
-    sh = stream.cuda_stream
     if use_dist:
-        # create the communicator now (RCCL does it lazily at the first collective and takes seconds):
-        # otherwise the first barrier in front of the timed region idles the GPU long enough for its
-        # clocks to drop, and the timed steps would run through the post-idle ramp
         warm = torch.zeros(1, dtype=torch.int64, device=dev)
         all_reduce_sum(warm)
         dist.barrier()
@@ -197,6 +279,20 @@ def main() -> None:
                 fn()
             torch.cuda.synchronize()
 
+    def step_distribution(fn, k):
+        """Per-step durations (ms) of k further steps, each bracketed by its own pair of events, in a SEPARATE untimed
+        pass: event markers between back-to-back 100-us kernels cost a few us of gap each, so they stay out of the
+        timed region, whose mean comes from one event pair around all K steps."""
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(k + 1)]
+        for i in range(k):
+            evs[i].record(stream)
+            fn()
+        evs[k].record(stream)
+        torch.cuda.synchronize()
+        d = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(k)])
+        return {"steps": k, "median": round(float(np.median(d)), 5), "min": round(float(d.min()), 5), "max": round(float(d.max()), 5),
+                "note": "separate untimed pass with an event marker between steps"}
+
     prewarm(step)
     for _ in range(args.warmup):
         step()
@@ -207,7 +303,7 @@ def main() -> None:
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev0.record(stream)
-    for _ in range(args.steps):
+    for _ in range(args.steps):  # EXACTLY K steps
         step()
     ev1.record(stream)
     total_count = count
@@ -217,23 +313,27 @@ def main() -> None:
     t1 = time.perf_counter()
     elapsed = shd.max_over_ranks(t1 - t0, dev)
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # average launch duration on the kernel's stream
+    count_after_timed = int(total_count.item())
+    step_ms = step_distribution(step, min(args.steps, 100))
     pairs_total = n * world * args.steps
     value = pairs_total / elapsed
-    collide_rate = float(total_count.item()) / (n * world * args.steps)
+    collide_rate = count_after_timed / (n * world * args.steps)
 
     achieved_gbs = BYTES_PER_PAIR * n / (kernel_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "sat_rect_verts_traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             if int(tj.get("pairs", 0)) == n:
                 traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = "recorded, not measured in this run: %s (2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes)" % tj.get("source")
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": "sat_rect_verts_kernel<4, 64>", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": BYTES_PER_PAIR * n, "kernel_ms": round(kernel_ms, 5)}
+                "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                "algorithmic_bytes_per_launch": BYTES_PER_PAIR * n, "kernel_ms": round(kernel_ms, 5),
+                "step_ms_distribution": step_ms}
 
     # ---- secondary input format: poses (41 B/pair), reported separately ----------
     pose_leg = None
@@ -252,10 +352,19 @@ def main() -> None:
         pe1.record(stream)
         torch.cuda.synchronize()
         pms = pe0.elapsed_time(pe1) / args.steps
+        pose_gbs = 41 * n / (pms * 1e-3) / 1e9
         pose_leg = {"metric": "sat_pair_tests_per_s (pose format, per GPU)", "value": n / (pms * 1e-3), "kernel_ms": round(pms, 5),
-                    "bytes_per_pair": 41, "achieved_GBs": round(41 * n / (pms * 1e-3) / 1e9, 1),
-                    "frac_of_hbm_peak": round(41 * n / (pms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "bytes_per_pair": 41,
+                    "roofline": {"bound": "hbm", "kernel": "sat_rect_pose_kernel<4, 64>", "achieved": round(pose_gbs, 1), "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": round(pose_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                                 "step_ms_distribution": step_distribution(pose_step, min(args.steps, 100))},
                     "note": "rectangles rebuilt from (cx,cy,w,h,theta) per pair: ~400 VALU instr per 41 B, VALU and HBM both near their roofs"}
+        c = counts.get("sat_rect_pose.config2")
+        if c and n == c.get("pairs"):
+            lane = n / (pms * 1e-3) * c["valu_instr_per_pair"] / 1e12
+            pose_leg["valu_roofline"] = {"bound": "valu", "achieved": round(lane, 2), "peak": VALU_PEAK_TLANE, "unit": "T VALU lane-instr/s",
+                                         "frac": round(lane / VALU_PEAK_TLANE, 4), "valu_instr_per_pair": c["valu_instr_per_pair"],
+                                         "instr_source": c.get("source")}
     del pose
 
     # ---- Monte-Carlo leg: config 3 --------------------------------------------------------
@@ -292,13 +401,13 @@ def main() -> None:
         mc = {"metric": "mc_samples_per_s", "value": S * world * args.mc_reps / mel, "samples_per_gpu": S, "reps": args.mc_reps,
               "kernel_ms": round(mc_kernel_ms, 4), "probability": p, "scene": "config3: robot 4.07x1.74 at (3,1) th=0.6, obstacle 2x1, sigma=(.3,.3,.2,0,0)",
               "bound": "valu", "note": "~0 HBM bytes per sample; VALU/transcendental bound (DESIGN.md)"}
-
-    if mc is not None:
-        # average VALU instructions per sample of this scene, measured with the SQ_INSTS_VALU counter
-        lane_ops = mc["value"] / world * VALU_INSTR_PER_SAMPLE / 1e12
-        mc["roofline"] = {"bound": "valu", "achieved": round(lane_ops, 2), "peak": FP32_VALU_PEAK_TFLOPS / 2,
-                          "unit": "T VALU lane-instr/s per GPU (peak = 157.3 TFLOP/s / 2 flop per FMA)",
-                          "frac": round(lane_ops / (FP32_VALU_PEAK_TFLOPS / 2), 4), "valu_instr_per_sample": VALU_INSTR_PER_SAMPLE}
+        c = counts.get("mc_pair.config3")
+        if c:  # the count belongs to THIS scene (wl.MC_PAIR_SCENE) and kernel build
+            lane_ops = S / (mc_kernel_ms * 1e-3) * c["valu_instr_per_sample"] / 1e12
+            mc["roofline"] = {"bound": "valu", "achieved": round(lane_ops, 2), "peak": VALU_PEAK_TLANE,
+                              "unit": "T VALU lane-instr/s per GPU (peak = 157.3 TFLOP/s / 2 flop per FMA)",
+                              "frac": round(lane_ops / VALU_PEAK_TLANE, 4), "valu_instr_per_sample": c["valu_instr_per_sample"],
+                              "instr_source": c.get("source")}
 
     # ---- config 4: adaptive Monte-Carlo over many scenes -------------------------------------
     scenes_leg = None
@@ -313,20 +422,34 @@ def main() -> None:
         eng.synchronize(sh)
         barrier()
         s0 = time.perf_counter()
+        se0, se1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        se0.record(stream)
         total, iters = eng.mc_scenes(d_p, 65536, d_s, 65536, d_sc, ns, 4.07, 1.74, wl.DEFAULT_BINS, wl.DEFAULT_BIN_ACCURACY,
                                      args.scenes_max_samples, 11, base, d_h, d_u, None, stream=sh)
+        se1.record(stream)
         hsum = torch.zeros(2, dtype=torch.int64, device=dev)
         hsum[0] = int(d_h.get().astype(np.int64).sum())
         hsum[1] = total
+        local_total = total
         all_reduce_sum(hsum)  # hit and sample totals: the one collective
         torch.cuda.synchronize()
         barrier()
         sel = shd.max_over_ranks(time.perf_counter() - s0, dev)
+        loop_ms = se0.elapsed_time(se1)
         scenes_leg = {"metric": "mc_samples_per_s", "value": float(hsum[1].item()) / sel, "data_points_per_gpu": ns,
                       "max_samples": args.scenes_max_samples, "schedule_steps": iters, "seconds": round(sel, 4),
+                      "device_loop_ms": round(loop_ms, 3),
                       "data_points_per_s": ns * world / sel, "mean_samples_per_point": float(hsum[1].item()) / (ns * world),
                       "pooled_hit_fraction": float(hsum[0].item()) / float(hsum[1].item()),
                       "workload": "config4: scenes drawn by the generate_dataset formula from 65536-entry tables, adaptive stopping"}
+        c = counts.get("mc_scenes.config4")
+        if c and ns == c.get("data_points") and args.scenes_max_samples == c.get("max_samples"):
+            lane = local_total / (loop_ms * 1e-3) * c["valu_instr_per_sample"] / 1e12
+            scenes_leg["roofline"] = {"bound": "valu", "kernel": "mc_scenes_advance_kernel (all schedule steps)", "achieved": round(lane, 2),
+                                      "peak": VALU_PEAK_TLANE, "unit": "T VALU lane-instr/s per GPU", "frac": round(lane / VALU_PEAK_TLANE, 4),
+                                      "valu_instr_per_sample": c["valu_instr_per_sample"], "instr_source": c.get("source"),
+                                      "note": "instructions per DRAWN sample: most samples of this workload are certain misses decided from "
+                                              "one Philox block (DESIGN.md §5); ~0 HBM bytes per sample"}
         for a_ in (d_p, d_s, d_sc, d_h, d_u):
             a_.free()
 
@@ -342,25 +465,46 @@ def main() -> None:
         def poly_step():
             eng.sat_poly_pairs(vx.data_ptr(), vy.data_ptr(), kk.data_ptr(), npoly, pout.data_ptr(), pcnt.data_ptr(), stream=sh)
 
-        for _ in range(3):
-            poly_step()
+        prewarm(poly_step)
         torch.cuda.synchronize()
         pcnt.zero_()
         barrier()
         torch.cuda.synchronize()
         p0 = time.perf_counter()
-        preps = 10
+        preps = args.poly_reps
+        q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        q0.record(stream)
         for _ in range(preps):
             poly_step()
+        q1.record(stream)
         all_reduce_sum(pcnt)
         torch.cuda.synchronize()
         barrier()
         pel = shd.max_over_ranks(time.perf_counter() - p0, dev)
+        eng.check_async()
+        poly_ms = q0.elapsed_time(q1) / preps
+        poly_collide = float(pcnt.item()) / (npoly * world * preps)
         exact_bytes = int(kk.to(torch.int64).sum().item()) * 8 + 3 * npoly
+        padded_gbs = 259 * npoly / (poly_ms * 1e-3) / 1e9
         poly_leg = {"metric": "poly_pair_tests_per_s", "value": npoly * world * preps / pel, "pairs_per_gpu": npoly, "reps": preps,
-                    "ms_per_pass": pel / preps * 1e3, "collide_rate": float(pcnt.item()) / (npoly * world * preps),
-                    "padded_GBs_per_gpu": 259 * npoly * preps / pel / 1e9, "exact_GBs_per_gpu": exact_bytes * preps / pel / 1e9,
-                    "bound": "valu/lds", "workload": "config5: K ~ U{3..16} convex polygons, SoA [2][16][n], true normals"}
+                    "ms_per_pass": pel / preps * 1e3, "kernel_ms": round(poly_ms, 5), "collide_rate": poly_collide,
+                    "roofline": {"bound": "hbm", "kernel": "sat_poly_kernel", "achieved": round(padded_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(padded_gbs / HBM_PEAK_GBS, 4),
+                                 "algorithmic_bytes_per_launch": 259 * npoly,
+                                 "bytes_note": "259 B/pair = the padded layout f32[2][16][n] x 2 + 2 count bytes + 1 result byte (SURVEY.md §8d); every "
+                                               "row below a wave's largest vertex count is read",
+                                 "exact_GBs": round(exact_bytes / (poly_ms * 1e-3) / 1e9, 1), "exact_frac": round(exact_bytes / (poly_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "traffic": None, "step_ms_distribution": step_distribution(poly_step, preps)},
+                    "workload": "config5: K ~ U{3..16} convex polygons, SoA [2][16][n], true normals"}
+        c = counts.get("sat_poly.config5")
+        if c and npoly == c.get("pairs"):
+            lane = npoly / (poly_ms * 1e-3) * c["valu_instr_per_pair"] / 1e12
+            poly_leg["valu_roofline"] = {"bound": "valu", "achieved": round(lane, 2), "peak": VALU_PEAK_TLANE, "unit": "T VALU lane-instr/s",
+                                         "frac": round(lane / VALU_PEAK_TLANE, 4), "valu_instr_per_pair": c["valu_instr_per_pair"],
+                                         "instr_source": c.get("source")}
+            if c.get("hbm_bytes_per_launch"):
+                poly_leg["roofline"]["traffic"] = c["hbm_bytes_per_launch"]
+                poly_leg["roofline"]["traffic_source"] = "recorded, not measured in this run: %s" % c.get("source")
         del vx, vy, kk, pout
 
     # ---- CPU baseline: oracle port on this host, rank 0, N = 1 only ------------------------------
@@ -404,12 +548,16 @@ def main() -> None:
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "config2: 1e7 random OBB pairs per GPU, 16 SoA vertex planes -> u8 booleans, single SAT overlap kernel",
                        "pairs_per_gpu": n, "bytes_per_pair": BYTES_PER_PAIR, "collide_rate": round(collide_rate, 5),
-                       "parallelism": f"pairs sharded over {world} GPU(s), one RCCL all-reduce of the hit count"},
+                       "parallelism": f"pairs sharded over {world} GPU(s), one process per GPU, no data-path collective, one sum of the hit count per leg",
+                       "reduce": reduce_impl,
+                       "ranks_in_reduce": (cdist.world_size if cdist is not None else (dist.get_world_size() if use_dist else 1))},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "pose_format": pose_leg, "mc": mc, "scenes": scenes_leg, "poly": poly_leg,
             "device": eng.info()["name"],
         }
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
+    if cdist is not None:
+        cdist.close()
     eng.close()
     if use_dist:
         dist.destroy_process_group()

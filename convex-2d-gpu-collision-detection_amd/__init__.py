@@ -12,6 +12,7 @@ load it with ``__graft_entry__.load_package()`` rather than a plain ``import``.
 from .binding import (  # noqa: F401
     C2DError,
     Engine,
+    Dist,
     DeviceArray,
     KMAX,
     POSE_DT,

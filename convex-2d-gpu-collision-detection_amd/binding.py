@@ -97,6 +97,16 @@ _SIGNATURES = {
     "c2d_mc_scenes": (C.c_int, [C.c_void_p, C.POINTER(_McScenesArgs), C.c_void_p]),
     "c2d_sample_scenes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_float,
                                     C.c_uint64, C.c_uint64, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "c2d_dist_unique_id": (C.c_int, [C.c_void_p]),
+    "c2d_dist_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "c2d_dist_init_file": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_double, C.POINTER(C.c_void_p)]),
+    "c2d_dist_rank": (C.c_int, [C.c_void_p]),
+    "c2d_dist_world_size": (C.c_int, [C.c_void_p]),
+    "c2d_dist_transport": (C.c_char_p, [C.c_void_p]),
+    "c2d_dist_all_reduce_sum_u64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "c2d_dist_broadcast_u64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "c2d_dist_barrier": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "c2d_dist_destroy": (C.c_int, [C.c_void_p]),
     "c2d_calc_slack": (C.c_float, [C.c_uint32, C.c_uint32]),
     "c2d_get_bin": (C.c_int, [C.c_float, C.POINTER(C.c_float), C.c_uint32]),
 }
@@ -143,6 +153,45 @@ class DeviceArray:
         if self.ptr:
             self.eng.free(self.ptr)
             self.ptr = 0
+
+
+DIST_ID_BYTES = 128
+
+
+class Dist:
+    """One c2d_dist: this rank's end of the RCCL communicator that sums the hit counters
+    (include/c2d.h, multi-GPU block).  Collective calls: every rank must make them."""
+
+    def __init__(self, eng: "Engine", handle):
+        self.eng, self.h = eng, handle
+
+    @property
+    def rank(self) -> int:
+        return int(self.eng.lib.c2d_dist_rank(self.h))
+
+    @property
+    def world_size(self) -> int:
+        return int(self.eng.lib.c2d_dist_world_size(self.h))
+
+    @property
+    def transport(self) -> str:
+        return self.eng.lib.c2d_dist_transport(self.h).decode()
+
+    def all_reduce_sum_u64(self, buf, count: int, stream: int = 0):
+        self.eng._check(self.eng.lib.c2d_dist_all_reduce_sum_u64(self.h, C.c_void_p(_ptr_of(buf)), count, C.c_void_p(stream)),
+                        "c2d_dist_all_reduce_sum_u64")
+
+    def broadcast_u64(self, buf, count: int, root: int = 0, stream: int = 0):
+        self.eng._check(self.eng.lib.c2d_dist_broadcast_u64(self.h, C.c_void_p(_ptr_of(buf)), count, root, C.c_void_p(stream)),
+                        "c2d_dist_broadcast_u64")
+
+    def barrier(self, stream: int = 0):
+        self.eng._check(self.eng.lib.c2d_dist_barrier(self.h, C.c_void_p(stream)), "c2d_dist_barrier")
+
+    def close(self):
+        if self.h:
+            self.eng.lib.c2d_dist_destroy(self.h)
+            self.h = None
 
 
 def _ptr_of(x) -> int:
@@ -200,6 +249,27 @@ class Engine:
 
     def synchronize(self, stream: int = 0):
         self._check(self.lib.c2d_stream_synchronize(self.h, C.c_void_p(stream)), "c2d_stream_synchronize")
+
+    # -- multi-GPU ----------------------------------------------------------
+    def dist_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(DIST_ID_BYTES)
+        st = self.lib.c2d_dist_unique_id(buf)
+        if st != 0:
+            raise C2DError(st, "c2d_dist_unique_id", self.lib.c2d_status_string(st).decode())
+        return buf.raw
+
+    def dist_init(self, rank: int, world_size: int, unique_id: bytes) -> Dist:
+        if len(unique_id) != DIST_ID_BYTES:
+            raise ValueError("the communicator id has 128 bytes")
+        h = C.c_void_p()
+        buf = C.create_string_buffer(unique_id, DIST_ID_BYTES)
+        self._check(self.lib.c2d_dist_init(self.h, rank, world_size, buf, C.byref(h)), "c2d_dist_init")
+        return Dist(self, h)
+
+    def dist_init_file(self, rank: int, world_size: int, path: str, timeout_s: float = 300.0) -> Dist:
+        h = C.c_void_p()
+        self._check(self.lib.c2d_dist_init_file(self.h, rank, world_size, path.encode(), timeout_s, C.byref(h)), "c2d_dist_init_file")
+        return Dist(self, h)
 
     def check_async(self):
         """Raise if a kernel of this ctx reported an argument error since the last check (c2d_ctx_check_async)."""

@@ -16,6 +16,7 @@ const char* c2d_status_string(int status)
     case C2D_ERR_NO_DEVICE: return "no usable device";
     case C2D_ERR_NOMEM: return "out of memory";
     case C2D_ERR_UNSUPPORTED: return "unsupported argument combination";
+    case C2D_ERR_DIST: return "multi-GPU (RCCL) error";
     default: return "unknown status";
     }
 }
@@ -49,8 +50,7 @@ int c2d_ctx_create(int device, c2d_ctx** out)
         hipMemset(ctx->d_count_words, 0, C2D_COUNT_WORDS_BYTES) != hipSuccess || hipMalloc(&ctx->d_bins, 32 * sizeof(float)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pinned), 64, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&ctx->h_async_err), 64, hipHostMallocMapped) != hipSuccess ||
-        hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->d_async_err), ctx->h_async_err, 0) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ws_event, hipEventDisableTiming) != hipSuccess) {
+        hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->d_async_err), ctx->h_async_err, 0) != hipSuccess) {
         if (ctx->d_counters) (void)hipFree(ctx->d_counters);
         if (ctx->d_count_words) (void)hipFree(ctx->d_count_words);
         if (ctx->d_bins) (void)hipFree(ctx->d_bins);
@@ -75,7 +75,6 @@ int c2d_ctx_destroy(c2d_ctx* ctx)
     if (ctx->d_bins) (void)hipFree(ctx->d_bins);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->h_async_err) (void)hipHostFree(ctx->h_async_err);
-    if (ctx->ws_event) (void)hipEventDestroy(ctx->ws_event);
     delete ctx;
     return C2D_OK;
 }
@@ -157,6 +156,10 @@ int c2d_stream_destroy(c2d_ctx* ctx, c2d_stream stream)
     if (!ctx) return C2D_ERR_INVALID_ARG;
     if (!stream) return C2D_OK;
     c2d::DeviceGuard g(ctx->device);
+    if (ctx->ws_busy && ctx->ws_stream == (hipStream_t)stream) {  // the workspace guard must not query a dead handle
+        C2D_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+        ctx->ws_busy = false;
+    }
     C2D_HIP(ctx, hipStreamDestroy((hipStream_t)stream));
     return C2D_OK;
 }

@@ -1,0 +1,322 @@
+// c2d_dist.hip — multi-GPU aggregation of the hit counters (include/c2d.h, "multi-GPU" block).
+//
+// The reference is single-GPU (compute_collision_probability.cu:212-251); BASELINE's north star
+// shards pairs / scenes / MC sample ranges over the 8 GPUs of a node — no exchange on the data
+// path — and closes with ONE sum-reduction of a few 64-bit counters.  That reduction is RCCL
+// (ncclAllReduce, uint64, sum) over xGMI; the payload is 8..64 bytes, so it is latency-bound
+// and link bandwidth is irrelevant.
+//
+// One process per GPU.  librccl.so.1 (573 MB) is dlopen'ed at the first c2d_dist_* call, so a
+// single-GPU run never loads it; inside a PyTorch process the already-loaded librccl of the same
+// soname is reused.  The 128-byte ncclUniqueId travels by whatever channel the caller has
+// (c2d_dist_init) or through a file (c2d_dist_init_file: rank 0 writes it atomically, the others wait).
+//
+// Rehearsal transport: RCCL refuses two ranks on one device ("Duplicate GPU detected"), so the
+// N > 1 host logic cannot be exercised with RCCL on a one-GPU box.  C2D_DIST_TRANSPORT=file selects
+// a file-based sum (host copies of the counters exchanged through files next to the id file) that
+// lets several ranks share a device.  It exists for tests only and reports itself as
+// "file (rehearsal)"; the default and the measured path is "rccl".
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <rccl/rccl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdlib>
+#include <thread>
+#include <vector>
+
+#include "c2d_internal.hpp"
+
+static_assert(sizeof(ncclUniqueId) == C2D_DIST_ID_BYTES, "C2D_DIST_ID_BYTES must match ncclUniqueId");
+
+namespace {
+
+struct Rccl {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+    std::string error;
+};
+
+Rccl& rccl()
+{
+    static Rccl r;
+    if (r.handle || !r.error.empty()) return r;
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+        r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (r.handle) break;
+    }
+    if (!r.handle) {
+        r.error = std::string("cannot load librccl.so.1: ") + dlerror();
+        return r;
+    }
+    auto sym = [&](const char* n) {
+        void* p = dlsym(r.handle, n);
+        if (!p && r.error.empty()) r.error = std::string("librccl lacks ") + n;
+        return p;
+    };
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+    r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
+    r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(sym("ncclGetVersion"));
+    if (!r.error.empty()) {
+        dlclose(r.handle);
+        r.handle = nullptr;
+    }
+    return r;
+}
+
+bool file_transport_selected()
+{
+    const char* t = std::getenv("C2D_DIST_TRANSPORT");
+    return t && std::string(t) == "file";
+}
+
+const char kFileMagic[] = "c2d-file-transport:";
+
+bool write_file_atomically(const std::string& path, const void* data, size_t bytes)
+{
+    const std::string tmp = path + ".tmp." + std::to_string((long long)getpid());
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return false;
+    const bool ok = std::fwrite(data, 1, bytes, f) == bytes;
+    if (std::fclose(f) != 0 || !ok) { std::remove(tmp.c_str()); return false; }
+    if (std::rename(tmp.c_str(), path.c_str()) != 0) { std::remove(tmp.c_str()); return false; }
+    return true;
+}
+
+// waits until `path` exists with exactly `bytes` bytes and reads it
+bool read_file_when_complete(const std::string& path, void* data, size_t bytes, double timeout_s)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        struct stat st;
+        if (stat(path.c_str(), &st) == 0 && (size_t)st.st_size == bytes) {
+            FILE* f = std::fopen(path.c_str(), "rb");
+            if (f) {
+                const bool ok = std::fread(data, 1, bytes, f) == bytes;
+                std::fclose(f);
+                if (ok) return true;
+            }
+        }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return false;
+        std::this_thread::sleep_for(std::chrono::microseconds(300));
+    }
+}
+
+}  // namespace
+
+struct c2d_dist {
+    c2d_ctx* ctx = nullptr;
+    int rank = 0, world = 1;
+    bool file = false;
+    ncclComm_t comm = nullptr;
+    std::string base;      // file transport: path prefix of the exchange files
+    uint64_t seq = 0;      // file transport: collective sequence number
+    double timeout_s = 300.0;
+};
+
+namespace {
+
+int fail_dist(c2d_ctx* ctx, const std::string& msg, int code = C2D_ERR_DIST)
+{
+    if (ctx) ctx->last_error = msg;
+    return code;
+}
+
+// file transport: sum of `count` host words over all ranks, in place
+int file_all_reduce(c2d_dist* d, unsigned long long* h, size_t count)
+{
+    const size_t bytes = count * sizeof(unsigned long long);
+    auto name = [&](uint64_t seq, int rank) { return d->base + "." + std::to_string(seq) + "." + std::to_string(rank); };
+    if (!write_file_atomically(name(d->seq, d->rank), h, bytes)) return fail_dist(d->ctx, "file transport: cannot write " + name(d->seq, d->rank));
+    std::vector<unsigned long long> other(count);
+    for (int r = 0; r < d->world; r++) {
+        if (r == d->rank) continue;
+        if (!read_file_when_complete(name(d->seq, r), other.data(), bytes, d->timeout_s))
+            return fail_dist(d->ctx, "file transport: timed out waiting for rank " + std::to_string(r) + " (payload sizes must agree on all ranks)");
+        for (size_t i = 0; i < count; i++) h[i] += other[i];
+    }
+    // A rank that writes sequence s has read every file of s - 1, so every rank has written s - 1 and hence
+    // finished reading s - 2: this rank's file of s - 2 has no reader left.
+    if (d->seq >= 2) std::remove(name(d->seq - 2, d->rank).c_str());
+    d->seq++;
+    return C2D_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int c2d_dist_unique_id(void* id_out)
+{
+    if (!id_out) return C2D_ERR_INVALID_ARG;
+    std::memset(id_out, 0, C2D_DIST_ID_BYTES);
+    if (file_transport_selected()) {
+        const char* dir = std::getenv("TMPDIR");
+        const auto now = std::chrono::steady_clock::now().time_since_epoch().count();
+        std::snprintf(static_cast<char*>(id_out), C2D_DIST_ID_BYTES, "%s%s/c2d_dist_%lld_%lld", kFileMagic, dir && *dir ? dir : "/tmp",
+                      (long long)getpid(), (long long)now);
+        return C2D_OK;
+    }
+    Rccl& R = rccl();
+    if (!R.handle) return C2D_ERR_DIST;
+    ncclUniqueId id;
+    if (R.GetUniqueId(&id) != ncclSuccess) return C2D_ERR_DIST;
+    std::memcpy(id_out, &id, sizeof id);
+    return C2D_OK;
+}
+
+int c2d_dist_init(c2d_ctx* ctx, int rank, int world_size, const void* id, c2d_dist** out)
+{
+    if (!ctx || !out || !id) return C2D_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (world_size < 1 || rank < 0 || rank >= world_size) return c2d::fail_arg(ctx, "c2d_dist_init: rank / world_size out of range");
+    c2d_dist* d = new (std::nothrow) c2d_dist();
+    if (!d) return C2D_ERR_NOMEM;
+    d->ctx = ctx;
+    d->rank = rank;
+    d->world = world_size;
+    const char* idc = static_cast<const char*>(id);
+    const size_t ml = sizeof(kFileMagic) - 1;
+    if (std::strncmp(idc, kFileMagic, ml) == 0) {
+        d->file = true;
+        d->base = std::string(idc + ml, strnlen(idc + ml, C2D_DIST_ID_BYTES - ml));
+        if (const char* t = std::getenv("C2D_DIST_TIMEOUT_S")) d->timeout_s = std::atof(t);
+        *out = d;
+        return C2D_OK;
+    }
+    Rccl& R = rccl();
+    if (!R.handle) { delete d; return fail_dist(ctx, R.error); }
+    c2d::DeviceGuard g(ctx->device);
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof uid);
+    const ncclResult_t st = R.CommInitRank(&d->comm, world_size, uid, rank);
+    if (st != ncclSuccess) {
+        delete d;
+        return fail_dist(ctx, std::string("ncclCommInitRank failed: ") + R.GetErrorString(st));
+    }
+    *out = d;
+    return C2D_OK;
+}
+
+int c2d_dist_init_file(c2d_ctx* ctx, int rank, int world_size, const char* path, double timeout_s, c2d_dist** out)
+{
+    if (!ctx || !out || !path || !*path) return C2D_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (world_size < 1 || rank < 0 || rank >= world_size) return c2d::fail_arg(ctx, "c2d_dist_init_file: rank / world_size out of range");
+    if (timeout_s <= 0) timeout_s = 300.0;
+    unsigned char id[C2D_DIST_ID_BYTES];
+    if (rank == 0) {
+        int st = c2d_dist_unique_id(id);
+        if (st != C2D_OK) return fail_dist(ctx, rccl().error.empty() ? "ncclGetUniqueId failed" : rccl().error);
+        if (!write_file_atomically(path, id, sizeof id)) return fail_dist(ctx, std::string("cannot write the id file ") + path);
+    } else if (!read_file_when_complete(path, id, sizeof id, timeout_s)) {
+        return fail_dist(ctx, std::string("timed out waiting for rank 0 to write the id file ") + path);
+    }
+    int st = c2d_dist_init(ctx, rank, world_size, id, out);
+    if (st != C2D_OK) return st;
+    (*out)->timeout_s = timeout_s;
+    // every rank has read the id once the first collective completes: rank 0 then removes the file
+    st = c2d_dist_barrier(*out, nullptr);
+    if (st != C2D_OK) { c2d_dist_destroy(*out); *out = nullptr; return st; }
+    if (rank == 0) std::remove(path);
+    return C2D_OK;
+}
+
+int c2d_dist_rank(const c2d_dist* d) { return d ? d->rank : -1; }
+
+int c2d_dist_world_size(const c2d_dist* d)
+{
+    if (!d) return -1;
+    if (d->file) return d->world;
+    int n = -1;  // what RCCL itself says about the communicator
+    if (rccl().CommCount(d->comm, &n) != ncclSuccess) return -1;
+    return n;
+}
+
+const char* c2d_dist_transport(const c2d_dist* d) { return !d ? "" : (d->file ? "file (rehearsal)" : "rccl"); }
+
+int c2d_dist_all_reduce_sum_u64(c2d_dist* d, unsigned long long* d_buf, size_t count, c2d_stream stream)
+{
+    if (!d || (!d_buf && count)) return C2D_ERR_INVALID_ARG;
+    if (count == 0) return C2D_OK;
+    c2d::DeviceGuard g(d->ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    if (d->file) {
+        std::vector<unsigned long long> h(count);
+        C2D_HIP(d->ctx, hipMemcpyAsync(h.data(), d_buf, count * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        C2D_HIP(d->ctx, hipStreamSynchronize(s));
+        if (int st = file_all_reduce(d, h.data(), count)) return st;
+        C2D_HIP(d->ctx, hipMemcpyAsync(d_buf, h.data(), count * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+        C2D_HIP(d->ctx, hipStreamSynchronize(s));
+        return C2D_OK;
+    }
+    const ncclResult_t st = rccl().AllReduce(d_buf, d_buf, count, ncclUint64, ncclSum, d->comm, s);
+    if (st != ncclSuccess) return fail_dist(d->ctx, std::string("ncclAllReduce failed: ") + rccl().GetErrorString(st));
+    return C2D_OK;
+}
+
+int c2d_dist_broadcast_u64(c2d_dist* d, unsigned long long* d_buf, size_t count, int root, c2d_stream stream)
+{
+    if (!d || (!d_buf && count) || root < 0 || root >= d->world) return C2D_ERR_INVALID_ARG;
+    if (count == 0) return C2D_OK;
+    c2d::DeviceGuard g(d->ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    if (d->file) {  // sum with zeros from everyone but the root
+        if (d->rank != root) C2D_HIP(d->ctx, hipMemsetAsync(d_buf, 0, count * sizeof(unsigned long long), s));
+        return c2d_dist_all_reduce_sum_u64(d, d_buf, count, stream);
+    }
+    const ncclResult_t st = rccl().Broadcast(d_buf, d_buf, count, ncclUint64, root, d->comm, s);
+    if (st != ncclSuccess) return fail_dist(d->ctx, std::string("ncclBroadcast failed: ") + rccl().GetErrorString(st));
+    return C2D_OK;
+}
+
+int c2d_dist_barrier(c2d_dist* d, c2d_stream stream)
+{
+    if (!d) return C2D_ERR_INVALID_ARG;
+    c2d::DeviceGuard g(d->ctx->device);
+    unsigned long long* w = nullptr;
+    C2D_HIP(d->ctx, hipMalloc(&w, sizeof *w));
+    int st = C2D_OK;
+    if (hipMemsetAsync(w, 0, sizeof *w, (hipStream_t)stream) != hipSuccess) st = C2D_ERR_HIP;
+    if (st == C2D_OK) st = c2d_dist_all_reduce_sum_u64(d, w, 1, stream);
+    if (st == C2D_OK && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) st = C2D_ERR_HIP;
+    (void)hipFree(w);
+    return st;
+}
+
+int c2d_dist_destroy(c2d_dist* d)
+{
+    if (!d) return C2D_OK;
+    if (d->file) {
+        // own exchange files of the last two sequence numbers may remain; the peers are past reading them
+        // once they have entered destroy too, which a final barrier establishes
+        if (d->world > 1) {
+            unsigned long long z = 0;
+            (void)file_all_reduce(d, &z, 1);
+        }
+        for (uint64_t s = d->seq >= 3 ? d->seq - 3 : 0; s < d->seq; s++)
+            if (s + 1 < d->seq || d->world == 1) std::remove((d->base + "." + std::to_string(s) + "." + std::to_string(d->rank)).c_str());
+        // the file of the final barrier itself is left for the slowest reader; it is a few bytes in TMPDIR
+    } else if (d->comm) {
+        c2d::DeviceGuard g(d->ctx->device);
+        (void)rccl().CommDestroy(d->comm);
+    }
+    delete d;
+    return C2D_OK;
+}
+
+}  // extern "C"

@@ -24,9 +24,8 @@ struct c2d_ctx {
     // c2d_ctx_check_async read and clear it, so asynchronous entry points need no validation pass.
     uint32_t* h_async_err = nullptr;
     uint32_t* d_async_err = nullptr;           // device address of the same word
-    // Guard of the shared workspace (count words, adaptive state, survivor lists): the last call that used
-    // it recorded ws_event on ws_stream; a workspace call on another stream before that event completed is refused.
-    hipEvent_t ws_event = nullptr;
+    // Guard of the shared workspace (count words, adaptive state, survivor lists): the stream of the last call that
+    // used it; a workspace call on another stream while that stream still has work queued is refused.
     hipStream_t ws_stream = nullptr;
     bool ws_busy = false;
     mutable std::string last_error;
@@ -83,15 +82,18 @@ struct DeviceGuard {
 
 constexpr int kMaxGrid = 1 << 24;  // blocks per launch; kernels grid-stride beyond it
 
-// See c2d_ctx::ws_event.  Calls on ONE stream are ordered by the stream; the guard only refuses a call that would
-// run concurrently with an unfinished one on a different stream (C2D_ERR_UNSUPPORTED instead of silent corruption).
+// Guard of the ctx workspace.  Calls on ONE stream are ordered by the stream; a workspace call on another stream is only
+// accepted once everything queued on the previous workspace stream has completed (hipStreamQuery: a host-side check that
+// puts nothing into either stream — an event per call costs a few microseconds of gap between back-to-back 100-us
+// kernels).  Otherwise it returns C2D_ERR_UNSUPPORTED instead of silently corrupting both calls.
 inline int workspace_acquire(c2d_ctx* ctx, hipStream_t s, bool uses)
 {
     if (!uses || !ctx->ws_busy || ctx->ws_stream == s) return C2D_OK;
-    if (hipEventQuery(ctx->ws_event) == hipErrorNotReady) {
+    if (hipStreamQuery(ctx->ws_stream) == hipErrorNotReady) {
         ctx->last_error = "this c2d_ctx still has a call in flight on another stream (one workspace per ctx: use one ctx per stream)";
         return C2D_ERR_UNSUPPORTED;
     }
+    (void)hipGetLastError();  // a stream the caller has destroyed meanwhile reads as an invalid handle: nothing in flight
     ctx->ws_busy = false;
     return C2D_OK;
 }
@@ -99,16 +101,8 @@ inline int workspace_acquire(c2d_ctx* ctx, hipStream_t s, bool uses)
 inline void workspace_release(c2d_ctx* ctx, hipStream_t s, bool uses)
 {
     if (!uses) return;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
-        (void)hipGetLastError();
-        ctx->ws_busy = false;  // inside a graph capture: ordering of graph launches is the caller's business
-        return;
-    }
-    if (hipEventRecord(ctx->ws_event, s) == hipSuccess) {
-        ctx->ws_stream = s;
-        ctx->ws_busy = true;
-    }
+    ctx->ws_stream = s;
+    ctx->ws_busy = true;
 }
 
 inline int grid_for(size_t work_items, int block, int max_blocks)

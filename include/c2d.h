@@ -48,6 +48,7 @@ extern "C" {
 #define C2D_ERR_NO_DEVICE (-3)    /* no usable gfx950 device / device index out of range */
 #define C2D_ERR_NOMEM (-4)        /* device or host allocation failed                    */
 #define C2D_ERR_UNSUPPORTED (-5)  /* argument combination outside the documented domain  */
+#define C2D_ERR_DIST (-6)         /* RCCL / multi-GPU set-up or collective failed        */
 
 typedef struct c2d_ctx c2d_ctx;
 typedef void* c2d_stream; /* hipStream_t */
@@ -260,6 +261,45 @@ int c2d_sample_scenes(c2d_ctx* ctx, const Pose* d_poses, uint32_t num_poses,
                       const StdDev* d_std_devs, uint32_t num_std_devs, float robot_w,
                       float robot_h, float spread, uint64_t seed, uint64_t scene_id_base,
                       size_t n_scenes, PositionWithVarAndPoseIdx* d_scenes, c2d_stream stream);
+
+/* ---- multi-GPU aggregation ----------------------------------------------------
+ * New work (the reference is single-GPU, compute_collision_probability.cu:212-251): pairs,
+ * scenes and Monte-Carlo sample ranges shard over the GPUs of a node with no exchange on
+ * the data path (random streams are keyed by scene id and sample index, so the union of
+ * the shards is bit-identical to a one-GPU run), and ONE sum-reduction of the 64-bit hit /
+ * sample / histogram counters closes a run.  One process per GPU; the reduction is
+ * ncclAllReduce(uint64, sum) of RCCL over xGMI, loaded (dlopen librccl.so.1) at the first
+ * c2d_dist_* call only.
+ *
+ *   c2d_dist_unique_id : rank 0 creates the 128-byte communicator id (ncclGetUniqueId) and
+ *                        hands it to the other ranks by any channel it has;
+ *   c2d_dist_init      : collective over all ranks (ncclCommInitRank) on the ctx's device;
+ *   c2d_dist_init_file : the same with the id exchanged through `path`: rank 0 writes the
+ *                        file atomically, the others wait up to timeout_s seconds for it;
+ *                        `path` must not exist beforehand (use a fresh name per run) and is
+ *                        removed again once every rank has joined;
+ *   c2d_dist_all_reduce_sum_u64 / c2d_dist_broadcast_u64 : in place on device words,
+ *                        asynchronous on `stream` like every other entry point;
+ *   c2d_dist_barrier   : a one-word all-reduce followed by a stream synchronise.
+ *
+ * C2D_DIST_TRANSPORT=file in the environment selects a rehearsal transport (host copies of
+ * the counters summed through small files) that lets several ranks share one device, which
+ * RCCL refuses; c2d_dist_transport() names the transport in use ("rccl" is the product path). */
+#define C2D_DIST_ID_BYTES 128
+typedef struct c2d_dist c2d_dist;
+int c2d_dist_unique_id(void* id_out /* [C2D_DIST_ID_BYTES] */);
+int c2d_dist_init(c2d_ctx* ctx, int rank, int world_size, const void* id, c2d_dist** out);
+int c2d_dist_init_file(c2d_ctx* ctx, int rank, int world_size, const char* path, double timeout_s,
+                       c2d_dist** out);
+int c2d_dist_rank(const c2d_dist* dist);
+int c2d_dist_world_size(const c2d_dist* dist); /* as counted by RCCL (ncclCommCount) */
+const char* c2d_dist_transport(const c2d_dist* dist);
+int c2d_dist_all_reduce_sum_u64(c2d_dist* dist, unsigned long long* d_buf, size_t count,
+                                c2d_stream stream);
+int c2d_dist_broadcast_u64(c2d_dist* dist, unsigned long long* d_buf, size_t count, int root,
+                           c2d_stream stream);
+int c2d_dist_barrier(c2d_dist* dist, c2d_stream stream);
+int c2d_dist_destroy(c2d_dist* dist);
 
 /* Host-side helpers with the reference's semantics, exported so that callers
  * and tests see exactly what the device evaluates (utils.cu:186-207). */
