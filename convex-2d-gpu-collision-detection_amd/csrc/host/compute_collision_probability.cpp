@@ -8,8 +8,11 @@
 // data_out (:157, :355).  Results come back in input order (scene i keeps slot i), so the
 // reference's index permutation (:224-228, :337-344) is not needed; --shuffle (default true)
 // then shuffles exactly as the reference does (:346-349).
-// Deliberate differences: hit counters are zeroed per batch (D4); --seed,
-// --rank / --world_size / --device are additions.
+// Deliberate differences: hit counters are zeroed per batch (D4).
+// Additions: --seed; --start_batch_count; multi-GPU (--gpus N, or one externally launched process per GPU with
+// --rank / --world_size / --device / --dist_id_file): batches are dealt round-robin and ONE RCCL sum of the counters
+// gives a single aggregated summary (rank 0); --pair_samples S runs BASELINE config 3 instead — one scene
+// (--pair_pos, --pair_pose, --pair_std_dev), S samples split over the ranks by sample index, hits summed, p printed.
 #include "driver_common.hpp"
 
 struct Arguments {  // defaults: compute_collision_probability.cu:35-42
@@ -20,7 +23,54 @@ struct Arguments {  // defaults: compute_collision_probability.cu:35-42
     float robot_height = 1.74;
     bool shuffle = true;
     unsigned long long seed = 0;
+    int start_batch_count = -1;          // -1: count the integer-named .npy files in data_out (:157)
+    unsigned long long pair_samples = 0; // > 0: single-scene mode (config 3)
+    std::vector<float> pair_pos = {3.0f, 1.0f};                       // robot position
+    std::vector<float> pair_pose = {2.0f, 1.0f, 0.6f};                 // obstacle width, height; robot theta (Pose)
+    std::vector<float> pair_std_dev = {0.3f, 0.3f, 0.2f, 0.0f, 0.0f};  // x, y, theta, width, height
 };
+
+// BASELINE config 3 over all ranks: the sample index space [0, S) is cut into contiguous ranges, one per rank
+// (the stream is keyed by the sample index, so the union is bit-identical to a one-GPU run), one RCCL sum of the
+// hit counts, p = hits / S.
+static int run_single_pair(const Arguments& a, const Shard& shard)
+{
+    c2d_ctx* ctx = nullptr;
+    C2D_CALL(ctx, c2d_ctx_create(shard.device, &ctx));
+    c2d_stream stream = nullptr;
+    C2D_CALL(ctx, c2d_stream_create(ctx, &stream));
+    DistLink link;
+    C2D_CALL(ctx, link.open(ctx, shard));
+    const unsigned long long S = a.pair_samples, W = static_cast<unsigned long long>(shard.world), r = static_cast<unsigned long long>(shard.rank);
+    const unsigned long long base = S / W, rem = S % W;
+    const unsigned long long begin = r * base + std::min(r, rem), count = base + (r < rem ? 1 : 0);
+    const Position pos{a.pair_pos[0], a.pair_pos[1]};
+    const Pose pose{a.pair_pose[0], a.pair_pose[1], a.pair_pose[2]};
+    const StdDev sd{a.pair_std_dev[0], a.pair_std_dev[1], a.pair_std_dev[2], a.pair_std_dev[3], a.pair_std_dev[4]};
+    void* d_hits = nullptr;
+    C2D_CALL(ctx, c2d_malloc(ctx, &d_hits, sizeof(unsigned long long)));
+    C2D_CALL(ctx, c2d_memset(ctx, d_hits, 0, sizeof(unsigned long long), stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    if (count) C2D_CALL(ctx, c2d_mc_pair(ctx, a.robot_width, a.robot_height, &pos, &pose, &sd, a.seed, 0, begin, count,
+                                         static_cast<unsigned long long*>(d_hits), stream));
+    unsigned long long w[3] = {0, count, 1};
+    C2D_CALL(ctx, c2d_memcpy_d2h(ctx, &w[0], d_hits, sizeof w[0], stream));
+    C2D_CALL(ctx, c2d_stream_synchronize(ctx, stream));
+    const double local_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    C2D_CALL(ctx, link.sum(w, 3, stream));  // the single RCCL reduce of the hit counts
+    const double total_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (shard.rank == 0 || !link.active())
+        std::printf("{\"tool\": \"compute_collision_probability\", \"mode\": \"single_pair\", \"rank\": %d, \"world_size\": %d, "
+                    "\"aggregated_over_ranks\": %llu, \"reduce\": \"%s\", \"samples\": %llu, \"hits\": %llu, \"p\": %.9f, "
+                    "\"seconds\": %.4f, \"rank_kernel_seconds\": %.4f, \"mc_samples_per_s\": %.4g}\n",
+                    shard.rank, shard.world, w[2], link.active() ? c2d_dist_transport(link.dist) : "none", w[1], w[0],
+                    w[1] ? static_cast<double>(w[0]) / static_cast<double>(w[1]) : 0.0, total_s, local_s, total_s > 0 ? w[1] / total_s : 0.0);
+    c2d_free(ctx, d_hits);
+    link.close();
+    c2d_stream_destroy(ctx, stream);
+    c2d_ctx_destroy(ctx);
+    return 0;
+}
 
 int main(int argc, char* argv[])
 {
@@ -35,10 +85,14 @@ int main(int argc, char* argv[])
     p.add("robot_height", 'h', K::VALUE, "robot height");
     p.add("shuffle", 0, K::VALUE, "whether or not to shuffle data");
     p.add("seed", 0, K::VALUE, "seed of the Monte-Carlo stream (default 0; the reference's std::rand() seed is fixed too, :249-251)");
-    p.add("rank", 0, K::VALUE, "this process' shard index (default: $RANK or 0)");
-    p.add("world_size", 0, K::VALUE, "number of shards = GPUs (default: $WORLD_SIZE or 1)");
-    p.add("device", 0, K::VALUE, "GPU index (default: $LOCAL_RANK or rank)");
+    p.add("start_batch_count", 0, K::VALUE, "number of the first output batch (default: the count of integer-named .npy in data_out)");
+    p.add("pair_samples", 0, K::VALUE, "single-scene mode: Monte-Carlo samples of ONE robot/obstacle pair, split over the GPUs; prints p");
+    p.add("pair_pos", 0, K::MULTI, "single-scene mode: robot position x y (default 3 1)");
+    p.add("pair_pose", 0, K::MULTI, "single-scene mode: obstacle width, height and robot theta (default 2 1 0.6)");
+    p.add("pair_std_dev", 0, K::MULTI, "single-scene mode: std dev of x y theta width height (default 0.3 0.3 0.2 0 0)");
+    add_shard_options(p);
     Shard shard;
+    int gpus = 1;
     try {
         p.parse(argc, argv);
         if (p.has("help")) { p.print_help(std::cout); return 1; }
@@ -49,17 +103,47 @@ int main(int argc, char* argv[])
         if (p.has("robot_height")) a.robot_height = p.real("robot_height");
         if (p.has("shuffle")) a.shuffle = p.boolean("shuffle");
         if (p.has("seed")) a.seed = std::stoull(p.str("seed"), nullptr, 0);
+        if (p.has("start_batch_count")) a.start_batch_count = p.integer("start_batch_count");
+        if (p.has("pair_samples")) a.pair_samples = std::stoull(p.str("pair_samples"), nullptr, 0);
+        auto take = [&](const char* name, std::vector<float>& dst, size_t nvals) {
+            if (!p.has(name)) return;
+            dst = p.reals(name);
+            if (dst.size() != nvals) throw std::runtime_error(std::string("--") + name + " needs " + std::to_string(nvals) + " values");
+        };
+        take("pair_pos", a.pair_pos, 2);
+        take("pair_pose", a.pair_pose, 3);
+        take("pair_std_dev", a.pair_std_dev, 5);
+        if (p.has("gpus")) gpus = p.integer("gpus");
         shard = resolve_shard(p);
         if (a.max_samples <= 0) throw std::runtime_error("--max_samples must be positive");
+        if (gpus < 1) throw std::runtime_error("--gpus must be at least 1");
+        if (gpus > 1 && shard.from_env) throw std::runtime_error("--gpus N starts the ranks itself: do not combine it with --rank / --world_size or a launcher");
     } catch (const std::exception& e) {
         std::cerr << "error: " << e.what() << "\n";
         p.print_help(std::cerr);
         return EXIT_FAILURE;
     }
-    const int start_batch_count = get_num_batches_in_dir(a.data_out);  // :157
+    if (a.pair_samples == 0 && a.start_batch_count < 0) {
+        // Ranks of a multi-GPU run must agree on the first output number.  Counting the directory per rank races with
+        // the ranks that already write into it, so it is counted ONCE: here by the launcher (--gpus N) or by a single
+        // process; externally launched ranks get it from rank 0 through the aggregation link (below) or must pass it.
+        if (shard.world > 1 && shard.id_file.empty()) {
+            std::cerr << "error: ranks launched by hand need --start_batch_count (or --dist_id_file / $C2D_DIST_ID_FILE, or use --gpus N)\n";
+            return EXIT_FAILURE;
+        }
+        a.start_batch_count = get_num_batches_in_dir(a.data_out);  // :157
+    }
+    if (gpus > 1) {
+        std::vector<std::string> extra;
+        if (a.pair_samples == 0) extra = {"--start_batch_count", std::to_string(a.start_batch_count)};
+        return launch_ranks(gpus, argc, argv, extra);
+    }
+    if (a.pair_samples > 0) return run_single_pair(a, shard);
+    int start_batch_count = a.start_batch_count;
     const int num_batches = get_num_batches_in_dir(a.data_in);         // :158
+    const bool chatty = shard.rank == 0;  // one rank narrates
 
-    std::cout << "Reading data..." << std::endl;
+    if (chatty) std::cout << "Reading data..." << std::endl;
     npy::Array poses, variances, first, accuracy_bins, bin_accuracy;
     try {
         poses = npy::load_f32(a.data_out + "/poses.npy");                    // :162-166
@@ -78,10 +162,12 @@ int main(int argc, char* argv[])
     const int num_poses = static_cast<int>(poses.data.size() / 3);
     const int num_variances = static_cast<int>(variances.data.size() / 5);
     const size_t N = first.data.size() / 4;  // taken from 0.npy and assumed for all batches (:164, :171)
-    std::cout << "num poses: " << num_poses << std::endl;
-    std::cout << "num variances: " << num_variances << std::endl;
-    std::cout << "num data points: " << N << std::endl;
-    if (num_batches == 0 || N == 0) { std::cout << "nothing to do" << std::endl; return 0; }
+    if (chatty) {
+        std::cout << "num poses: " << num_poses << std::endl;
+        std::cout << "num variances: " << num_variances << std::endl;
+        std::cout << "num data points: " << N << std::endl;
+    }
+    if (num_batches == 0 || N == 0) { if (chatty) std::cout << "nothing to do" << std::endl; return 0; }
     if (num_poses == 0 || num_variances == 0) { std::cerr << "error: empty pose / variance table\n"; return EXIT_FAILURE; }
     std::vector<StdDev> std_devs = std_devs_from_variances(variances.data);
 
@@ -89,6 +175,13 @@ int main(int argc, char* argv[])
     C2D_CALL(ctx, c2d_ctx_create(shard.device, &ctx));
     c2d_stream stream = nullptr;
     C2D_CALL(ctx, c2d_stream_create(ctx, &stream));
+    DistLink link;
+    C2D_CALL(ctx, link.open(ctx, shard));
+    if (link.active()) {  // rank 0's view of the output directory is everyone's
+        unsigned long long w[1] = {static_cast<unsigned long long>(start_batch_count)};
+        C2D_CALL(ctx, link.broadcast(w, 1, stream));
+        start_batch_count = static_cast<int>(w[0]);
+    }
     void *d_poses = nullptr, *d_sd = nullptr, *d_scenes = nullptr, *d_hits = nullptr, *d_used = nullptr, *d_rows = nullptr;
     C2D_CALL(ctx, c2d_malloc(ctx, &d_poses, poses.data.size() * sizeof(float)));
     C2D_CALL(ctx, c2d_malloc(ctx, &d_sd, std_devs.size() * sizeof(StdDev)));
@@ -103,11 +196,13 @@ int main(int argc, char* argv[])
     std::vector<PoseCPVarAndPoseIdx> dataset(N);
     std::vector<uint32_t> hits(N);
     const auto begin = std::chrono::steady_clock::now();
-    std::cout << "Total number of configurations: " << static_cast<long long>(N) * num_batches << std::endl;
-    std::cout << "Begin computation..." << std::endl;
+    if (chatty) {
+        std::cout << "Total number of configurations: " << static_cast<long long>(N) * num_batches << std::endl;
+        std::cout << "Begin computation..." << std::endl;
+    }
     int counter = 0;
     RunStats stats;
-    std::printf("batches generated: %i/%i\n", counter, num_batches);
+    if (chatty) std::printf("batches generated: %i/%i\n", counter, num_batches);
     for (int batch_index = shard.rank; batch_index < num_batches; batch_index += shard.world) {
         npy::Array batch;
         try {
@@ -153,20 +248,26 @@ int main(int argc, char* argv[])
             return EXIT_FAILURE;
         }
         const auto now = std::chrono::steady_clock::now();
-        std::printf("\33[2K\r");
-        std::printf("batches generated: %i/%i, Time: %i [min]", ++counter, num_batches,
-                    static_cast<int>(std::chrono::duration_cast<std::chrono::minutes>(now - begin).count()));
-        std::fflush(stdout);
+        ++counter;
+        if (chatty) {
+            std::printf("\33[2K\r");
+            std::printf("batches generated: %i/%i, Time: %i [min]", counter * shard.world < num_batches ? counter * shard.world : num_batches, num_batches,
+                        static_cast<int>(std::chrono::duration_cast<std::chrono::minutes>(now - begin).count()));
+            std::fflush(stdout);
+        }
     }
-    std::cout << std::endl;
+    if (chatty) std::cout << std::endl;
     const auto end = std::chrono::steady_clock::now();
     stats.seconds = std::chrono::duration<double>(end - begin).count();
-    std::cout << "Finished computation" << std::endl;
-    std::cout << "Elapsed time: " << std::chrono::duration_cast<std::chrono::minutes>(end - begin).count() << " [min]" << std::endl;
-    print_json_summary("compute_collision_probability", shard, stats, counter);
+    if (chatty) {
+        std::cout << "Finished computation" << std::endl;
+        std::cout << "Elapsed time: " << std::chrono::duration_cast<std::chrono::minutes>(end - begin).count() << " [min]" << std::endl;
+    }
+    C2D_CALL(ctx, print_json_summary("compute_collision_probability", shard, stats, counter, &link, stream));
     for (void* ptr : {d_poses, d_sd, d_scenes, d_hits, d_used, d_rows}) c2d_free(ctx, ptr);
+    link.close();
     c2d_stream_destroy(ctx, stream);
     c2d_ctx_destroy(ctx);
-    std::cout << "Done." << std::endl;
+    if (chatty) std::cout << "Done." << std::endl;
     return 0;
 }

@@ -60,21 +60,91 @@ struct Shard {
     int rank = 0;
     int world = 1;
     int device = 0;
+    std::string id_file;   // where the ranks exchange the RCCL id (c2d_dist_init_file); empty = no aggregation
+    bool from_env = false; // rank / world size came from a launcher's environment or from --rank / --world_size
 };
 
-// One process per GPU: rank / world size come from --rank / --world_size or from the
-// launcher's environment (RANK, WORLD_SIZE, LOCAL_RANK).  Batches are dealt round-robin,
-// every batch file is written by exactly one rank, so no collective is needed on the data path.
+// One process per GPU.  Rank / world size come from --rank / --world_size or from the launcher's environment
+// (RANK, WORLD_SIZE, LOCAL_RANK); `--gpus N` makes the driver its own launcher (launch_ranks below).  Batches are
+// dealt round-robin, every batch file is written by exactly one rank, so the data path needs no collective; the
+// run closes with one RCCL sum of the counters (DistLink) and rank 0 prints the aggregated summary.
 inline Shard resolve_shard(const cli::Parser& p)
 {
     Shard s;
     auto env_int = [](const char* k, int def) { const char* v = std::getenv(k); return v ? std::atoi(v) : def; };
+    s.from_env = p.has("world_size") || p.has("rank") || std::getenv("WORLD_SIZE") || std::getenv("RANK");
     s.world = p.has("world_size") ? p.integer("world_size") : env_int("WORLD_SIZE", 1);
     s.rank = p.has("rank") ? p.integer("rank") : env_int("RANK", 0);
     s.device = p.has("device") ? p.integer("device") : env_int("LOCAL_RANK", s.rank);
+    if (p.has("dist_id_file")) s.id_file = p.str("dist_id_file");
+    else if (const char* f = std::getenv("C2D_DIST_ID_FILE")) s.id_file = f;
     if (s.world < 1 || s.rank < 0 || s.rank >= s.world) throw std::runtime_error("bad --rank / --world_size");
     return s;
 }
+
+inline void add_shard_options(cli::Parser& p)
+{
+    using K = cli::Option;
+    p.add("gpus", 0, K::VALUE, "use N GPUs of this node: the driver starts one process per GPU itself and prints one aggregated summary");
+    p.add("rank", 0, K::VALUE, "this process' shard index (default: $RANK or 0)");
+    p.add("world_size", 0, K::VALUE, "number of shards = GPUs (default: $WORLD_SIZE or 1)");
+    p.add("device", 0, K::VALUE, "GPU index (default: $LOCAL_RANK or rank)");
+    p.add("dist_id_file", 0, K::VALUE, "fresh file through which externally launched ranks exchange the RCCL id (default: $C2D_DIST_ID_FILE)");
+}
+
+// `--gpus N`: this process becomes the launcher.  It has not touched a GPU (it only parsed flags and looked at
+// directories); it starts N fresh copies of itself, one per GPU, with RANK / WORLD_SIZE / LOCAL_RANK and a fresh
+// C2D_DIST_ID_FILE in their environment and `extra` appended to their arguments — values every rank must agree on
+// (first output batch number, seed) are resolved ONCE here, so ranks cannot race on them — waits for all of them and
+// returns the first non-zero exit status (remaining ranks are terminated when one fails).
+inline int launch_ranks(int n, int argc, char** argv, const std::vector<std::string>& extra);
+
+// The aggregation link of a rank: c2d_dist (RCCL) plus one small device buffer.
+struct DistLink {
+    c2d_ctx* ctx = nullptr;
+    c2d_dist* dist = nullptr;
+    unsigned long long* d_buf = nullptr;
+    static constexpr size_t kWords = 16;
+    int open(c2d_ctx* c, const Shard& sh)
+    {
+        ctx = c;
+        if (sh.world <= 1 && sh.id_file.empty()) return C2D_OK;
+        if (sh.id_file.empty()) return C2D_OK;  // externally launched without an id file: no aggregation (each rank reports itself)
+        int st = c2d_dist_init_file(ctx, sh.rank, sh.world, sh.id_file.c_str(), 300.0, &dist);
+        if (st != C2D_OK) return st;
+        return c2d_malloc(ctx, reinterpret_cast<void**>(&d_buf), kWords * sizeof(unsigned long long));
+    }
+    bool active() const { return dist != nullptr; }
+    // in-place sum over ranks of up to kWords host counters
+    int sum(unsigned long long* h, size_t count, c2d_stream stream)
+    {
+        if (!dist) return C2D_OK;
+        if (count > kWords) return C2D_ERR_INVALID_ARG;
+        int st = c2d_memcpy_h2d(ctx, d_buf, h, count * sizeof *h, stream);
+        if (st == C2D_OK) st = c2d_dist_all_reduce_sum_u64(dist, d_buf, count, stream);
+        if (st == C2D_OK) st = c2d_memcpy_d2h(ctx, h, d_buf, count * sizeof *h, stream);
+        if (st == C2D_OK) st = c2d_stream_synchronize(ctx, stream);
+        return st;
+    }
+    // rank 0's values to everyone
+    int broadcast(unsigned long long* h, size_t count, c2d_stream stream)
+    {
+        if (!dist) return C2D_OK;
+        if (count > kWords) return C2D_ERR_INVALID_ARG;
+        int st = c2d_memcpy_h2d(ctx, d_buf, h, count * sizeof *h, stream);
+        if (st == C2D_OK) st = c2d_dist_broadcast_u64(dist, d_buf, count, 0, stream);
+        if (st == C2D_OK) st = c2d_memcpy_d2h(ctx, h, d_buf, count * sizeof *h, stream);
+        if (st == C2D_OK) st = c2d_stream_synchronize(ctx, stream);
+        return st;
+    }
+    void close()
+    {
+        if (d_buf) c2d_free(ctx, d_buf);
+        if (dist) c2d_dist_destroy(dist);
+        d_buf = nullptr;
+        dist = nullptr;
+    }
+};
 
 inline std::vector<StdDev> std_devs_from_variances(const std::vector<float>& var_flat)
 {
@@ -110,10 +180,97 @@ struct RunStats {
     double seconds = 0;
 };
 
-inline void print_json_summary(const char* tool, const Shard& sh, const RunStats& st, int batches)
+// One line per run.  With an aggregation link it is printed by rank 0 only and holds the sums over all ranks
+// (samples, hits, scenes, batches, the cp histogram; seconds = the slowest rank's).
+inline int print_json_summary(const char* tool, const Shard& sh, RunStats st, int batches, DistLink* link, c2d_stream stream)
 {
-    std::printf("{\"tool\": \"%s\", \"rank\": %d, \"world_size\": %d, \"batches\": %d, \"scenes\": %llu, \"mc_samples\": %llu, "
+    const char* reduce = "none";
+    int ranks = 1;
+    if (link && link->active()) {
+        unsigned long long w[9] = {st.samples, st.hits, st.scenes, st.cp_hist[0], st.cp_hist[1], st.cp_hist[2], st.cp_hist[3],
+                                   static_cast<unsigned long long>(batches), 1ull};
+        int rc = link->sum(w, 9, stream);
+        if (rc != C2D_OK) return rc;
+        // wall time of the run = the slowest rank's: every rank puts its milliseconds into its own word of a second sum
+        if (sh.world <= static_cast<int>(DistLink::kWords)) {
+            unsigned long long ms[DistLink::kWords] = {};
+            ms[sh.rank] = static_cast<unsigned long long>(st.seconds * 1e3);
+            rc = link->sum(ms, static_cast<size_t>(sh.world), stream);
+            if (rc != C2D_OK) return rc;
+            st.seconds = static_cast<double>(*std::max_element(ms, ms + sh.world)) / 1e3;
+        }
+        st.samples = w[0]; st.hits = w[1]; st.scenes = w[2];
+        for (int i = 0; i < 4; i++) st.cp_hist[i] = w[3 + i];
+        batches = static_cast<int>(w[7]);
+        ranks = static_cast<int>(w[8]);
+        reduce = c2d_dist_transport(link->dist);
+        if (sh.rank != 0) return C2D_OK;
+    }
+    std::printf("{\"tool\": \"%s\", \"rank\": %d, \"world_size\": %d, \"aggregated_over_ranks\": %d, \"reduce\": \"%s\", \"batches\": %d, "
+                "\"scenes\": %llu, \"mc_samples\": %llu, \"hits\": %llu, \"pooled_probability\": %.9g, "
                 "\"seconds\": %.3f, \"mc_samples_per_s\": %.4g, \"cp_hist_bins\": [0, 0.001, 0.01, 0.1, 1], \"cp_hist\": [%llu, %llu, %llu, %llu]}\n",
-                tool, sh.rank, sh.world, batches, st.scenes, st.samples, st.seconds, st.seconds > 0 ? st.samples / st.seconds : 0.0,
-                st.cp_hist[0], st.cp_hist[1], st.cp_hist[2], st.cp_hist[3]);
+                tool, sh.rank, sh.world, ranks, reduce, batches, st.scenes, st.samples, st.hits,
+                st.samples ? static_cast<double>(st.hits) / static_cast<double>(st.samples) : 0.0, st.seconds,
+                st.seconds > 0 ? st.samples / st.seconds : 0.0, st.cp_hist[0], st.cp_hist[1], st.cp_hist[2], st.cp_hist[3]);
+    std::fflush(stdout);
+    return C2D_OK;
+}
+
+#include <signal.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+inline int launch_ranks(int n, int argc, char** argv, const std::vector<std::string>& extra)
+{
+    std::vector<std::string> args;
+    for (int i = 0; i < argc; i++) {
+        const std::string a = argv[i];
+        if (a == "--gpus") { i++; continue; }            // the children are plain ranks
+        if (a.rfind("--gpus=", 0) == 0) continue;
+        args.push_back(a);
+    }
+    for (const auto& e : extra) args.push_back(e);
+    char exe[4096];
+    const ssize_t len = readlink("/proc/self/exe", exe, sizeof exe - 1);
+    if (len <= 0) { std::fprintf(stderr, "error: cannot resolve /proc/self/exe\n"); return EXIT_FAILURE; }
+    exe[len] = 0;
+    const char* tmp = std::getenv("TMPDIR");
+    const std::string id_file = std::string(tmp && *tmp ? tmp : "/tmp") + "/c2d_dist_id_" + std::to_string(static_cast<long long>(getpid())) + "_" +
+                                std::to_string(static_cast<long long>(std::chrono::steady_clock::now().time_since_epoch().count()));
+    std::remove(id_file.c_str());
+    std::vector<pid_t> pids;
+    for (int r = 0; r < n; r++) {
+        const pid_t pid = fork();
+        if (pid < 0) { std::perror("fork"); break; }
+        if (pid == 0) {
+            setenv("RANK", std::to_string(r).c_str(), 1);
+            setenv("WORLD_SIZE", std::to_string(n).c_str(), 1);
+            if (!std::getenv("C2D_SHARE_DEVICE")) setenv("LOCAL_RANK", std::to_string(r).c_str(), 1);
+            else setenv("LOCAL_RANK", "0", 1);                      // rehearsal on a one-GPU box (with C2D_DIST_TRANSPORT=file)
+            setenv("C2D_DIST_ID_FILE", id_file.c_str(), 1);
+            setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
+            std::vector<char*> cargv;
+            for (auto& a : args) cargv.push_back(const_cast<char*>(a.c_str()));
+            cargv.push_back(nullptr);
+            execv(exe, cargv.data());
+            std::perror("execv");
+            _exit(127);
+        }
+        pids.push_back(pid);
+    }
+    int rc = static_cast<int>(pids.size()) == n ? 0 : EXIT_FAILURE;
+    size_t left = pids.size();
+    while (left > 0) {
+        int status = 0;
+        const pid_t done = wait(&status);
+        if (done < 0) break;
+        left--;
+        const int code = WIFEXITED(status) ? WEXITSTATUS(status) : 128 + (WIFSIGNALED(status) ? WTERMSIG(status) : 0);
+        if (code != 0 && rc == 0) {
+            rc = code;
+            for (pid_t p : pids) if (p != done) kill(p, SIGTERM);  // exact PIDs of our own children
+        }
+    }
+    std::remove(id_file.c_str());
+    return rc;
 }

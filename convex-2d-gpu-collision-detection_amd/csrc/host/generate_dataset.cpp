@@ -65,10 +65,9 @@ int main(int argc, char* argv[])
     p.add("pose_dir", 0, K::VALUE, "poses .npy file to load instead of sampling");
     p.add("variance_dir", 0, K::VALUE, "variances .npy file to load instead of sampling");
     p.add("seed", 0, K::VALUE, "seed of the scene / Monte-Carlo streams (default: time based)");
-    p.add("rank", 0, K::VALUE, "this process' shard index (default: $RANK or 0)");
-    p.add("world_size", 0, K::VALUE, "number of shards = GPUs (default: $WORLD_SIZE or 1)");
-    p.add("device", 0, K::VALUE, "GPU index (default: $LOCAL_RANK or rank)");
+    add_shard_options(p);
     Shard shard;
+    int gpus = 1;
     try {
         p.parse(argc, argv);
         if (p.has("help")) { p.print_help(std::cout); return 1; }
@@ -92,7 +91,10 @@ int main(int argc, char* argv[])
         if (p.has("pose_dir")) a.pose_dir = p.str("pose_dir");
         if (p.has("variance_dir")) a.variance_dir = p.str("variance_dir");
         if (p.has("seed")) { a.seed = std::stoull(p.str("seed"), nullptr, 0); a.seed_given = true; }
+        if (p.has("gpus")) gpus = p.integer("gpus");
         shard = resolve_shard(p);
+        if (gpus < 1) throw std::runtime_error("--gpus must be at least 1");
+        if (gpus > 1 && shard.from_env) throw std::runtime_error("--gpus N starts the ranks itself: do not combine it with --rank / --world_size or a launcher");
         if (a.accuracy_bins.size() < 2 || a.bin_accuracy.size() + 1 != a.accuracy_bins.size())
             throw std::runtime_error("--bin_accuracy needs one value fewer than --accuracy_bins");
         if (a.batch_size <= 0 || a.num_batches < 0 || a.max_samples <= 0) throw std::runtime_error("sizes must be positive");
@@ -101,11 +103,25 @@ int main(int argc, char* argv[])
         p.print_help(std::cerr);
         return EXIT_FAILURE;
     }
+    // The seed is part of every scene's random stream: all ranks must use the same one.  The default (time based, as
+    // the reference's srand(time(0)), :406) is therefore resolved ONCE — here by the launcher or the single process;
+    // externally launched ranks take rank 0's through the aggregation link (below) or must pass --seed.
+    if (!a.seed_given) {
+        if (shard.world > 1 && shard.id_file.empty()) {
+            std::cerr << "error: ranks launched by hand need --seed (or --dist_id_file / $C2D_DIST_ID_FILE, or use --gpus N)\n";
+            return EXIT_FAILURE;
+        }
+        a.seed = static_cast<unsigned long long>(std::time(nullptr));
+    }
+    if (gpus > 1) return launch_ranks(gpus, argc, argv, {"--seed", std::to_string(a.seed)});
+    const bool chatty = shard.rank == 0;  // one rank narrates
     const std::string& data_dir = a.data_dir;
-    std::cout << "data dir: " << data_dir << std::endl;
-    std::cout << "num batches: " << a.num_batches << std::endl;
-    std::cout << "num batch: " << a.batch_size << std::endl;
-    std::cout << "start batch count: " << a.start_batch_count << std::endl;
+    if (chatty) {
+        std::cout << "data dir: " << data_dir << std::endl;
+        std::cout << "num batches: " << a.num_batches << std::endl;
+        std::cout << "num batch: " << a.batch_size << std::endl;
+        std::cout << "start batch count: " << a.start_batch_count << std::endl;
+    }
 
     try {
         mkdirs(data_dir);            // reference creates these only after saving (D7)
@@ -161,16 +177,23 @@ int main(int argc, char* argv[])
     }
     if (a.num_poses <= 0 || a.num_variances <= 0) { std::cerr << "error: empty pose / variance table\n"; return EXIT_FAILURE; }
     std::vector<StdDev> std_devs = std_devs_from_variances(variances);
-    std::cout << "num poses: " << a.num_poses << std::endl;
-    std::cout << "num variances: " << a.num_variances << std::endl;
-
-    if (!a.seed_given) a.seed = static_cast<unsigned long long>(std::time(nullptr));  // reference: srand(time(0)), :406
-    std::cout << "seed: " << a.seed << std::endl;
+    if (chatty) {
+        std::cout << "num poses: " << a.num_poses << std::endl;
+        std::cout << "num variances: " << a.num_variances << std::endl;
+    }
 
     c2d_ctx* ctx = nullptr;
     C2D_CALL(ctx, c2d_ctx_create(shard.device, &ctx));
     c2d_stream stream = nullptr;
     C2D_CALL(ctx, c2d_stream_create(ctx, &stream));
+    DistLink link;
+    C2D_CALL(ctx, link.open(ctx, shard));
+    if (link.active()) {  // rank 0's seed is everyone's
+        unsigned long long w[1] = {a.seed};
+        C2D_CALL(ctx, link.broadcast(w, 1, stream));
+        a.seed = w[0];
+    }
+    if (chatty) std::cout << "seed: " << a.seed << std::endl;
     const size_t B = static_cast<size_t>(a.batch_size);
     void *d_poses = nullptr, *d_sd = nullptr, *d_scenes = nullptr, *d_hits = nullptr, *d_used = nullptr, *d_rows = nullptr;
     C2D_CALL(ctx, c2d_malloc(ctx, &d_poses, poses.size() * sizeof(float)));
@@ -186,11 +209,13 @@ int main(int argc, char* argv[])
     std::vector<PoseCPVarAndPoseIdx> dataset(B);
     std::vector<uint32_t> hits(B);
     const auto begin = std::chrono::steady_clock::now();
-    std::cout << "Total number of configurations: " << static_cast<long long>(a.batch_size) * a.num_batches << std::endl;
-    std::cout << "Begin computation..." << std::endl;
+    if (chatty) {
+        std::cout << "Total number of configurations: " << static_cast<long long>(a.batch_size) * a.num_batches << std::endl;
+        std::cout << "Begin computation..." << std::endl;
+    }
     int counter = 0;
     RunStats stats;
-    std::printf("batches generated: %i/%i", counter, a.num_batches);
+    if (chatty) std::printf("batches generated: %i/%i", counter, a.num_batches);
     for (int batch_index = shard.rank; batch_index < a.num_batches; batch_index += shard.world) {
         const uint64_t scene_base = (static_cast<uint64_t>(a.start_batch_count) + batch_index) * B;
         // iteration == 0 branch of the reference kernel: draw the scenes (:207-219)
@@ -227,20 +252,26 @@ int main(int argc, char* argv[])
             return EXIT_FAILURE;
         }
         const auto now = std::chrono::steady_clock::now();
-        std::printf("\33[2K\r");
-        std::printf("batches generated: %i/%i, Time: %i [min]", ++counter, a.num_batches,
-                    static_cast<int>(std::chrono::duration_cast<std::chrono::minutes>(now - begin).count()));
-        std::fflush(stdout);
+        ++counter;
+        if (chatty) {
+            std::printf("\33[2K\r");
+            std::printf("batches generated: %i/%i, Time: %i [min]", counter * shard.world < a.num_batches ? counter * shard.world : a.num_batches,
+                        a.num_batches, static_cast<int>(std::chrono::duration_cast<std::chrono::minutes>(now - begin).count()));
+            std::fflush(stdout);
+        }
     }
-    std::cout << std::endl;
+    if (chatty) std::cout << std::endl;
     const auto end = std::chrono::steady_clock::now();
     stats.seconds = std::chrono::duration<double>(end - begin).count();
-    std::cout << "Finished computation" << std::endl;
-    std::cout << "Elapsed time: " << std::chrono::duration_cast<std::chrono::minutes>(end - begin).count() << " [min]" << std::endl;
-    print_json_summary("generate_dataset", shard, stats, counter);
+    if (chatty) {
+        std::cout << "Finished computation" << std::endl;
+        std::cout << "Elapsed time: " << std::chrono::duration_cast<std::chrono::minutes>(end - begin).count() << " [min]" << std::endl;
+    }
+    C2D_CALL(ctx, print_json_summary("generate_dataset", shard, stats, counter, &link, stream));
     for (void* ptr : {d_poses, d_sd, d_scenes, d_hits, d_used, d_rows}) c2d_free(ctx, ptr);
+    link.close();
     c2d_stream_destroy(ctx, stream);
     c2d_ctx_destroy(ctx);
-    std::cout << "Done." << std::endl;
+    if (chatty) std::cout << "Done." << std::endl;
     return 0;
 }

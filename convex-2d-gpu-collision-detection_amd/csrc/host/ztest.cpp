@@ -145,7 +145,7 @@ int main(int argc, char* argv[])
     stats.samples = total; stats.scenes = N; stats.seconds = std::chrono::duration<double>(end - begin).count();
     std::cout << "Finished computation" << std::endl;
     std::cout << "Elapsed time: " << std::chrono::duration_cast<std::chrono::minutes>(end - begin).count() << " [min]" << std::endl;
-    print_json_summary("ztest", shard, stats, 1);
+    C2D_CALL(ctx, print_json_summary("ztest", shard, stats, 1, nullptr, stream));
     for (void* ptr : {d_poses, d_sd, d_scenes, d_hits, d_used, d_rows}) c2d_free(ctx, ptr);
     c2d_stream_destroy(ctx, stream);
     c2d_ctx_destroy(ctx);

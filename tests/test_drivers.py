@@ -41,6 +41,20 @@ def test_bad_flags_fail_cleanly(tmp_path):
     assert run([CCP, "--data_in", str(tmp_path / "nope"), "--data_out", str(tmp_path / "nope2")]).returncode != 0
 
 
+def test_multi_rank_flags_are_checked_before_any_gpu_work(tmp_path):
+    """Values all ranks must agree on are resolved once: hand-launched ranks without an aggregation link
+    must be given them; --gpus N (the driver launches its own ranks) excludes --rank / --world_size."""
+    out = run([GEN, "--data_dir", str(tmp_path / "a"), "--rank", "1", "--world_size", "2", "-n", "2", "-b", "10"])
+    assert out.returncode != 0 and "--seed" in out.stderr
+    out = run([CCP, "--data_in", str(tmp_path), "--data_out", str(tmp_path), "--rank", "1", "--world_size", "2"])
+    assert out.returncode != 0 and "--start_batch_count" in out.stderr
+    for tool in (GEN, CCP):
+        out = run([tool, "--gpus", "2", "--rank", "0", "--world_size", "2"])
+        assert out.returncode != 0 and "starts the ranks itself" in out.stderr
+        assert run([tool, "--gpus", "0"]).returncode != 0
+    assert "--gpus" in run([GEN, "--help"]).stdout and "--pair_samples" in run([CCP, "--help"]).stdout
+
+
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="CPU-only behaviour")
 def test_generate_dataset_writes_tables_then_fails_loudly_without_gpu(tmp_path):
     d = tmp_path / "data"

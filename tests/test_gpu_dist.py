@@ -1,0 +1,193 @@
+"""Multi-GPU path on the one-GPU test box.
+
+What CAN run here and does:
+  * c2d_dist with the real RCCL transport and a world of one rank (dlopen of librccl.so.1, ncclGetUniqueId,
+    ncclCommInitRank, ncclAllReduce / ncclBroadcast on device words, the id-file exchange);
+  * the N > 1 host logic of the C++ drivers and of bench.py with two ranks that SHARE device 0 and sum their
+    counters through the file rehearsal transport (C2D_DIST_TRANSPORT=file) — RCCL itself refuses two ranks on
+    one device ("Duplicate GPU detected"), so two-rank RCCL needs the multi-GPU node the round-end driver uses.
+The property under test everywhere: shards + one sum reproduce the single-process result exactly (random streams
+are keyed by scene id and sample index)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "convex-2d-gpu-collision-detection_amd", "bin")
+GEN = os.path.join(BIN, "generate_dataset")
+CCP = os.path.join(BIN, "compute_collision_probability")
+REHEARSAL = {"C2D_DIST_TRANSPORT": "file", "C2D_SHARE_DEVICE": "1"}
+
+
+def run(cmd, env=None, **kw):
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=e, **kw)
+
+
+def summary_of(out):
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout + out.stderr          # ONE aggregated line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_c2d_dist_rccl_single_rank(eng, pkg, tmp_path):
+    """The product transport end to end with a world of one: id by bytes and id by file."""
+    d = eng.dist_init(0, 1, eng.dist_unique_id())
+    assert d.transport == "rccl" and d.rank == 0 and d.world_size == 1
+    buf = eng.to_device(np.array([5, 2**40 + 7, 0], np.uint64))
+    d.all_reduce_sum_u64(buf, 3)
+    d.broadcast_u64(buf, 3, root=0)
+    d.barrier()
+    assert buf.get().tolist() == [5, 2**40 + 7, 0]
+    d.close()
+    path = str(tmp_path / "id")
+    d2 = eng.dist_init_file(0, 1, path, 30.0)
+    assert d2.transport == "rccl" and not os.path.exists(path)   # the id file is removed once everyone joined
+    d2.all_reduce_sum_u64(buf, 3)
+    eng.synchronize()
+    assert buf.get().tolist() == [5, 2**40 + 7, 0]
+    d2.close()
+    buf.free()
+    with pytest.raises(pkg.C2DError):
+        eng.dist_init(1, 1, eng.dist_unique_id())               # rank out of range
+
+
+def test_generate_dataset_two_ranks_equal_one_rank(tmp_path):
+    args = ["-n", "5", "-b", "900", "-s", "2", "--num_poses", "200", "--num_variances", "100", "--max_samples", "3000", "--seed", "77",
+            "--spread", "3.5"]
+    one = run([GEN, "--data_dir", str(tmp_path / "one")] + args)
+    assert one.returncode == 0, one.stderr
+    two = run([GEN, "--data_dir", str(tmp_path / "two"), "--gpus", "2"] + args, env=REHEARSAL)
+    assert two.returncode == 0, two.stderr + two.stdout
+    s1, s2 = summary_of(one), summary_of(two)
+    assert s2["world_size"] == 2 and s2["aggregated_over_ranks"] == 2 and "file" in s2["reduce"]
+    for key in ("batches", "scenes", "mc_samples", "hits", "cp_hist"):
+        assert s1[key] == s2[key], key
+    names = sorted(p.name for p in (tmp_path / "one").glob("[0-9]*.npy"))
+    assert names == [f"{k}.npy" for k in range(2, 7)]
+    for nme in names + ["poses.npy", "variances.npy"]:
+        assert np.array_equal(np.load(tmp_path / "one" / nme).view(np.uint32), np.load(tmp_path / "two" / nme).view(np.uint32)), nme
+
+
+def test_generate_dataset_default_seed_is_resolved_once(tmp_path):
+    """Without --seed the launcher picks the time-based seed and hands the same one to every rank."""
+    out = run([GEN, "--data_dir", str(tmp_path / "d"), "--gpus", "2", "-n", "2", "-b", "300", "--num_poses", "50", "--num_variances", "50",
+               "--max_samples", "2000"], env=REHEARSAL)
+    assert out.returncode == 0, out.stderr
+    seeds = [ln for ln in out.stdout.splitlines() if ln.startswith("seed:")]
+    assert len(seeds) == 1                                      # rank 0 narrates; one seed
+    # hand-launched ranks without a seed and without a link must refuse instead of diverging
+    bad = run([GEN, "--data_dir", str(tmp_path / "e"), "--rank", "0", "--world_size", "2", "-n", "2", "-b", "300"])
+    assert bad.returncode != 0 and "--seed" in bad.stderr
+
+
+def _ccp_inputs(tmp_path, wl, n_batches=5, N=500):
+    din, dout = tmp_path / "in", tmp_path / "out"
+    din.mkdir()
+    poses, sds, var = wl.random_tables(50, 40, seed=3)
+    rng = np.random.default_rng(1)
+    for k in range(n_batches):
+        s = np.empty((N, 4), np.float32)
+        s[:, 0] = rng.uniform(-6, 6, N)
+        s[:, 1] = rng.uniform(-6, 6, N)
+        s[:, 2] = rng.integers(0, 40, N)
+        s[:, 3] = rng.integers(0, 50, N)
+        np.save(din / f"{k}.npy", s)
+
+    def fresh_out(name):
+        d = tmp_path / name
+        (d / "meta").mkdir(parents=True)
+        np.save(d / "poses.npy", poses.view(np.float32).reshape(-1, 3))
+        np.save(d / "variances.npy", var)
+        np.save(d / "meta" / "accuracy_bins.npy", np.array([0, .01, .1, 1], np.float32))
+        np.save(d / "meta" / "bin_accuracy.npy", np.array([1e-4, 1e-3, 1e-2], np.float32))
+        np.save(d / "0.npy", np.zeros((3, 5), np.float32))       # an existing batch: numbering continues at 1
+        return d
+
+    return din, fresh_out
+
+
+def test_ccp_two_ranks_equal_one_rank_both_launch_styles(tmp_path, wl):
+    din, fresh_out = _ccp_inputs(tmp_path, wl)
+    common = ["--data_in", str(din), "--max_samples", "4000", "--seed", "9"]
+    d1 = fresh_out("one")
+    one = run([CCP, "--data_out", str(d1)] + common)
+    assert one.returncode == 0, one.stderr
+    s1 = summary_of(one)
+    # (a) the driver launches its own ranks
+    d2 = fresh_out("two")
+    two = run([CCP, "--data_out", str(d2), "--gpus", "2"] + common, env=REHEARSAL)
+    assert two.returncode == 0, two.stderr + two.stdout
+    # (b) two processes started by hand (as a launcher would), id file given, NO --start_batch_count: rank 0's count is
+    # broadcast, so the late starter cannot mis-number its files (racy start_batch_count)
+    d3 = fresh_out("three")
+    env = dict(os.environ, C2D_DIST_TRANSPORT="file", WORLD_SIZE="2", LOCAL_RANK="0", C2D_DIST_ID_FILE=str(tmp_path / "idfile"))
+    p0 = subprocess.Popen([CCP, "--data_out", str(d3)] + common, env=dict(env, RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    p1 = subprocess.Popen([CCP, "--data_out", str(d3)] + common, env=dict(env, RANK="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    o0, e0 = p0.communicate(timeout=600)
+    o1, e1 = p1.communicate(timeout=600)
+    assert p0.returncode == 0 and p1.returncode == 0, e0 + e1
+    assert not [ln for ln in o1.splitlines() if ln.startswith("{")]            # only rank 0 prints the summary
+    s3 = json.loads([ln for ln in o0.splitlines() if ln.startswith("{")][-1])
+    s2 = summary_of(two)
+    for s in (s2, s3):
+        assert s["aggregated_over_ranks"] == 2
+        for key in ("batches", "scenes", "mc_samples", "hits", "cp_hist"):
+            assert s1[key] == s[key], key
+    for d in (d2, d3):
+        assert sorted(p.name for p in d.glob("[0-9]*.npy")) == [f"{k}.npy" for k in range(0, 6)]
+        for k in range(1, 6):
+            assert np.array_equal(np.load(d1 / f"{k}.npy").view(np.uint32), np.load(d / f"{k}.npy").view(np.uint32)), k
+    # hand-launched ranks with neither a link nor --start_batch_count refuse
+    bad = run([CCP, "--data_out", str(d3), "--rank", "1", "--world_size", "2"] + common)
+    assert bad.returncode != 0 and "--start_batch_count" in bad.stderr
+
+
+def test_ccp_single_pair_mode_sharded_equals_oracle(oracle, wl):
+    """BASELINE config 3 through the driver: S samples of one scene split over ranks by sample index, one sum."""
+    sc = wl.MC_PAIR_SCENE
+    S = 3_000_001
+    ref = oracle.mc_pair(sc["robot_w"], sc["robot_h"], sc["pos"], sc["pose"], sc["std_dev"], 1234, 0, 0, S)
+    one = run([CCP, "--pair_samples", str(S), "--seed", "1234"])
+    assert one.returncode == 0, one.stderr
+    s1 = summary_of(one)
+    two = run([CCP, "--pair_samples", str(S), "--seed", "1234", "--gpus", "2"], env=REHEARSAL)
+    assert two.returncode == 0, two.stderr
+    s2 = summary_of(two)
+    assert s1["hits"] == ref == s2["hits"] and s1["samples"] == S == s2["samples"]
+    assert s2["aggregated_over_ranks"] == 2 and abs(s2["p"] - ref / S) < 1e-9
+    # the product transport with one rank: --dist_id_file makes a world of one go through RCCL
+    rc = run([CCP, "--pair_samples", "100000", "--seed", "5", "--dist_id_file", "/tmp/c2d_test_id_%d" % os.getpid()])
+    assert rc.returncode == 0, rc.stderr
+    assert summary_of(rc)["reduce"] == "rccl"
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` without a launcher (how the round-end driver calls it): rehearsed with two ranks
+    sharing the device (gloo rendezvous + file transport), and with one rank through the real RCCL reduce."""
+    small = ["--steps", "3", "--warmup", "1", "--pairs", "1000000", "--mc-samples", "1000000", "--mc-reps", "1", "--scenes", "20000",
+             "--scenes-max-samples", "3000", "--poly-pairs", "200000", "--poly-reps", "2", "--no-cpu-baseline", "--prewarm-ms", "5"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--backend", "gloo"] + small,
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["ranks_in_reduce"] == 2 and "c2d_dist" in j["config"]["reduce"]
+    assert abs(j["mc"]["probability"] - 0.5537) < 5e-3 and j["poly"]["collide_rate"] > 0.03
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist"] + small, capture_output=True, text=True, timeout=900,
+                         env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = json.loads(out.stdout.strip().splitlines()[-1])
+    assert j["n_gpus"] == 1 and "rccl" in j["config"]["reduce"]
+    # a failing rank must fail the launcher
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--backend", "gloo", "--pairs", "-5"] + small[6:],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode != 0 and not out.stdout.strip()
