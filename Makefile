@@ -11,7 +11,7 @@ SRCS := $(CSRC)/c2d_api.hip $(CSRC)/c2d_sat.hip $(CSRC)/c2d_poly.hip $(CSRC)/c2d
 OBJS := $(SRCS:.hip=.o)
 HDRS := $(CSRC)/c2d_math.hpp $(CSRC)/c2d_count.hpp $(CSRC)/c2d_internal.hpp include/c2d.h include/utils.h
 
-all: lib oracle drivers
+all: lib oracle drivers lib-fmad lib-nopretest
 
 lib: $(LIBDIR)/libc2d.so
 
@@ -38,7 +38,7 @@ clean:
 	rm -f $(OBJS) $(LIBDIR)/libc2d.so $(BINDIR)/generate_dataset $(BINDIR)/compute_collision_probability $(BINDIR)/ztest
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle drivers tools clean
+.PHONY: all lib oracle drivers tools clean lib-fmad lib-nopretest
 
 # developer tools (not shipped in libc2d.so)
 TOOLS := $(CSRC)/tools/sat_tune
@@ -46,7 +46,17 @@ tools: $(TOOLS)
 $(CSRC)/tools/%: $(CSRC)/tools/%.hip $(HDRS)
 	$(HIPCC) -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -Iinclude $< -o $@
 
-# validation build: Monte-Carlo kernels without the certain-miss pretests (tools/validate_pretest.py)
-lib-nopretest: $(LIBDIR)/libc2d.so
-	$(HIPCC) $(HIPFLAGS) -DC2D_MC_NO_PRETEST -c $(CSRC)/c2d_mc.hip -o $(CSRC)/c2d_mc_nopretest.o
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $(LIBDIR)/libc2d_nopretest.so $(CSRC)/c2d_api.o $(CSRC)/c2d_sat.o $(CSRC)/c2d_poly.o $(CSRC)/c2d_dist.o $(CSRC)/c2d_mc_nopretest.o -ldl
+# validation build: Monte-Carlo kernels without the certain-miss pretests (tests/test_gpu_fullsize.py, tools/validate_*.py)
+lib-nopretest: $(LIBDIR)/libc2d_nopretest.so
+$(CSRC)/c2d_mc_nopretest.o: $(CSRC)/c2d_mc.hip $(HDRS)
+	$(HIPCC) $(HIPFLAGS) -DC2D_MC_NO_PRETEST -c $< -o $@
+$(LIBDIR)/libc2d_nopretest.so: $(OBJS) $(CSRC)/c2d_mc_nopretest.o
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(filter-out $(CSRC)/c2d_mc.o,$(OBJS)) $(CSRC)/c2d_mc_nopretest.o -ldl
+
+# validation builds: the reference's dot products contracted as nvcc -fmad=true might (C2D_FMAD in c2d_math.hpp);
+# only used to measure the distance from the canonical arithmetic (tests/test_gpu_fmad.py)
+lib-fmad: $(LIBDIR)/libc2d_fmad1.so $(LIBDIR)/libc2d_fmad2.so
+$(LIBDIR)/libc2d_fmad%.so: $(SRCS) $(HDRS)
+	@mkdir -p $(LIBDIR) build/fmad$*
+	for f in $(SRCS); do $(HIPCC) $(HIPFLAGS) -DC2D_FMAD=$* -c $$f -o build/fmad$*/$$(basename $$f .hip).o || exit 1; done
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ build/fmad$*/*.o -ldl

@@ -114,20 +114,23 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 
+def _open_library(path: str) -> C.CDLL:
+    if not os.path.exists(path):
+        raise C2DError(-3, "libc2d.so not built", f"run `make lib` or __graft_entry__.build(); expected {path}")
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
 def load_library() -> C.CDLL:
     """dlopen lib/libc2d.so and type every entry point.  Raises if the HIP
     library has not been built: there is no fallback."""
     global _lib
     if _lib is None:
-        path = library_path()
-        if not os.path.exists(path):
-            raise C2DError(-3, "libc2d.so not built", f"run `make lib` or __graft_entry__.build(); expected {path}")
-        lib = C.CDLL(path)
-        for name, (res, args) in _SIGNATURES.items():
-            fn = getattr(lib, name)  # AttributeError if the symbol is missing
-            fn.restype = res
-            fn.argtypes = args
-        _lib = lib
+        _lib = _open_library(library_path())
     return _lib
 
 
@@ -205,8 +208,9 @@ def _ptr_of(x) -> int:
 class Engine:
     """One c2d_ctx (one device)."""
 
-    def __init__(self, device: int = 0):
-        self.lib = load_library()
+    def __init__(self, device: int = 0, lib_path: Optional[str] = None):
+        # lib_path: another build of the same C-ABI (validation builds such as lib/libc2d_fmad1.so)
+        self.lib = _open_library(lib_path) if lib_path else load_library()
         h = C.c_void_p()
         st = self.lib.c2d_ctx_create(device, C.byref(h))
         if st != 0:

@@ -161,6 +161,25 @@ C2D_DEV void box_muller(uint32_t x, uint32_t y, float& n0, float& n1)
 
 // ---- geometry -------------------------------------------------------------------
 
+// The reference's two-product sums a*x + b*y (utils.cu:139-140 rotation, :173-174 projection).  C2D_FMAD = 0 is the
+// canonical arithmetic of the product: two roundings for the products, one for the sum.  C2D_FMAD = 1 / 2 exist only in
+// the validation builds (`make lib-fmad`): the two forms nvcc's default -fmad=true can give a CUDA build of the reference
+// (left or right product fused), used to MEASURE the distance between the canonical choice and such a build
+// (oracle/tools/fmad_study.py, tests/test_gpu_fmad.py).
+#ifndef C2D_FMAD
+#define C2D_FMAD 0
+#endif
+C2D_DEV float dot2(float a, float x, float b, float y)
+{
+#if C2D_FMAD == 1
+    return fma_(a, x, b * y);
+#elif C2D_FMAD == 2
+    return fma_(b, y, a * x);
+#else
+    return a * x + b * y;
+#endif
+}
+
 // create_rect (reference utils.cu:119-130) followed by rot_trans_rectangle
 // (utils.cu:132-142) with cos/sin given.  The four vertices of a box with half
 // extents (hx, hy) are (-+hx, -+hy); since rounding is sign-symmetric the
@@ -168,8 +187,16 @@ C2D_DEV void box_muller(uint32_t x, uint32_t y, float& n0, float& n1)
 // exactly to the shared products below.
 C2D_DEV void rect_from_half_extents(float hx, float hy, float c, float s, float dx, float dy, float (&r)[8])
 {
+#if C2D_FMAD == 1   // x' = fma(c, x, -(s*y)), y' = fma(s, x, c*y); fma is sign-symmetric too
+    float b = s * hy, q = c * hy;
+    float t1 = fma_(c, hx, b), t2 = fma_(c, hx, -b), t3 = fma_(s, hx, q), t4 = fma_(s, hx, -q);
+#elif C2D_FMAD == 2 // x' = fma(-s, y, c*x), y' = fma(c, y, s*x)
+    float a = c * hx, p = s * hx;
+    float t1 = fma_(s, hy, a), t2 = fma_(-s, hy, a), t3 = fma_(c, hy, p), t4 = fma_(-c, hy, p);
+#else
     float a = c * hx, b = s * hy, p = s * hx, q = c * hy;
     float t1 = a + b, t2 = a - b, t3 = p + q, t4 = p - q;
+#endif
     r[0] = dx - t2;  // (-a) - (-b) + dx
     r[1] = dy - t3;  // (-p) + (-q) + dy
     r[2] = t1 + dx;  //   a  - (-b) + dx
@@ -186,10 +213,10 @@ C2D_DEV float max4(float a, float b, float c, float d) { return __builtin_fmaxf(
 // One SAT axis (reference utils.cu:172-180): unfused dots, strict <.
 C2D_DEV bool axis_separates(float ax, float ay, const float (&r1)[8], const float (&r2)[8])
 {
-    float p10 = ax * r1[0] + ay * r1[1], p11 = ax * r1[2] + ay * r1[3];
-    float p12 = ax * r1[4] + ay * r1[5], p13 = ax * r1[6] + ay * r1[7];
-    float p20 = ax * r2[0] + ay * r2[1], p21 = ax * r2[2] + ay * r2[3];
-    float p22 = ax * r2[4] + ay * r2[5], p23 = ax * r2[6] + ay * r2[7];
+    float p10 = dot2(ax, r1[0], ay, r1[1]), p11 = dot2(ax, r1[2], ay, r1[3]);
+    float p12 = dot2(ax, r1[4], ay, r1[5]), p13 = dot2(ax, r1[6], ay, r1[7]);
+    float p20 = dot2(ax, r2[0], ay, r2[1]), p21 = dot2(ax, r2[2], ay, r2[3]);
+    float p22 = dot2(ax, r2[4], ay, r2[5]), p23 = dot2(ax, r2[6], ay, r2[7]);
     float min1 = min4(p10, p11, p12, p13), max1 = max4(p10, p11, p12, p13);
     float min2 = min4(p20, p21, p22, p23), max2 = max4(p20, p21, p22, p23);
     return (max1 < min2) || (max2 < min1);

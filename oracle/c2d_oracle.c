@@ -40,6 +40,28 @@
 #define C2D_MC_LARGE_BATCH 100000
 #define C2D_MC_SWITCH_AT 20000
 
+/* C2D_ORACLE_FMAD selects how the reference's two-product sums a*x + b*y (utils.cu:139-140, :173-174) are rounded:
+ *   0 (canonical, default)  fadd(fmul(a,x), fmul(b,y))       — what the c2d kernels compute;
+ *   1                       fma(a, x, fmul(b,y))             — nvcc -fmad=true fusing the LEFT product;
+ *   2                       fma(b, y, fmul(a,x))             — nvcc -fmad=true fusing the RIGHT product.
+ * nvcc's default is -fmad=true and which product ptxas fuses cannot be observed here (no CUDA), so 1 and 2 exist
+ * only to MEASURE how far the canonical choice can be from a CUDA build of the reference (oracle/tools/fmad_study.py,
+ * DESIGN.md §2); everything else in this file is identical across the three builds. */
+#ifndef C2D_ORACLE_FMAD
+#define C2D_ORACLE_FMAD 0
+#endif
+static inline float dot2(float a, float x, float b, float y)
+{
+#if C2D_ORACLE_FMAD == 1
+    return fmaf(a, x, b * y);
+#elif C2D_ORACLE_FMAD == 2
+    return fmaf(b, y, a * x);
+#else
+    return a * x + b * y;
+#endif
+}
+int c2d_oracle_fmad_variant(void) { return C2D_ORACLE_FMAD; }
+
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
@@ -226,8 +248,8 @@ void c2d_oracle_rot_trans_rectangle(float* r, float dx, float dy, float dt)
     for (int i = 0; i < 4; i++) {
         float x = r[2 * i];
         float y = r[2 * i + 1];
-        r[2 * i] = c * x - s * y + dx;
-        r[2 * i + 1] = s * x + c * y + dy;
+        r[2 * i] = dot2(c, x, -s, y) + dx;     /* c*x - s*y + dx: (-s)*y == -(s*y) exactly */
+        r[2 * i + 1] = dot2(s, x, c, y) + dy;
     }
 }
 
@@ -272,8 +294,8 @@ int c2d_oracle_convex_collide(const float* r1, const float* r2)
             norm[0] = r[(i + 1) * 2 % 8] - r[i * 2];
             norm[1] = r[((i + 1) * 2 + 1) % 8] - r[i * 2 + 1];
             for (int k = 0; k < 4; k++) {
-                p1[k] = norm[0] * r1[k * 2] + norm[1] * r1[k * 2 + 1];
-                p2[k] = norm[0] * r2[k * 2] + norm[1] * r2[k * 2 + 1];
+                p1[k] = dot2(norm[0], r1[k * 2], norm[1], r1[k * 2 + 1]);
+                p2[k] = dot2(norm[0], r2[k * 2], norm[1], r2[k * 2 + 1]);
             }
             float min1, max1, min2, max2;
             minmax4(p1, &min1, &max1);

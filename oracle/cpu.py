@@ -11,7 +11,10 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libc2d_oracle.so")
+# "" = the canonical arithmetic; "fmad1" / "fmad2" = the contraction-study builds (load_variant below)
+_VARIANT = globals().get("_VARIANT", "")
+_LIB_NAME = "libc2d_oracle%s.so" % ("_" + _VARIANT if _VARIANT else "")
+_LIB_PATH = os.path.join(_HERE, _LIB_NAME)
 KMAX = 16
 
 
@@ -38,9 +41,26 @@ def build(force: bool = False) -> str:
     """Compile the oracle with its Makefile if the .so is missing or stale."""
     src = os.path.join(_HERE, "c2d_oracle.c")
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.run(["make", "-C", _HERE, "-B", "libc2d_oracle.so"], check=True,
+        subprocess.run(["make", "-C", _HERE, "-B", _LIB_NAME], check=True,
                        stdout=subprocess.DEVNULL)
     return _LIB_PATH
+
+
+def load_variant(name: str):
+    """A second copy of this module bound to libc2d_oracle_<name>.so (name: "fmad1" or "fmad2"): the same
+    restatement with the reference's dot products contracted the way nvcc -fmad=true might (C2D_ORACLE_FMAD)."""
+    import importlib.util
+    import sys
+
+    modname = __name__ + "_" + name
+    if modname in sys.modules:
+        return sys.modules[modname]
+    spec = importlib.util.spec_from_file_location(modname, os.path.abspath(__file__))
+    m = importlib.util.module_from_spec(spec)
+    m._VARIANT = name
+    sys.modules[modname] = m
+    spec.loader.exec_module(m)
+    return m
 
 
 _lib = None

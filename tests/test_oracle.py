@@ -247,3 +247,30 @@ def test_hypothesis_numpy_and_c_oracles_agree_on_arbitrary_floats(oracle):
         assert c == oracle.convex_collide(r2, r1)
 
     check()
+
+
+def test_contraction_variants_of_the_oracle(oracle, wl):
+    """oracle/libc2d_oracle_fmad{1,2}.so: the reference's dot products contracted as nvcc -fmad=true might
+    (oracle/tools/fmad_study.py holds the full-size study).  Small-size facts: the golden config-1 booleans do not
+    depend on the convention; pairs built ON the decision boundary do; Monte-Carlo counts move by a handful."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sat_rect_1k.npz"))
+    planes = np.ascontiguousarray(g["planes"])
+    ref, _ = oracle.sat_rect_pairs_verts(planes)
+    poses = wl.random_obb_pose_planes(200_000, seed=0x5A7)
+    pref, _ = oracle.sat_rect_pairs_pose(poses)
+    sc = wl.MC_PAIR_SCENE
+    href = oracle.mc_pair(sc["robot_w"], sc["robot_h"], sc["pos"], sc["pose"], sc["std_dev"], 1234, 0, 0, 1_000_000)
+    for k in (1, 2):
+        v = oracle.load_variant(f"fmad{k}")
+        assert v.lib().c2d_oracle_fmad_variant() == k and oracle.lib().c2d_oracle_fmad_variant() == 0
+        out, _ = v.sat_rect_pairs_verts(planes)
+        assert np.array_equal(out, ref) and np.array_equal(out, g["expected"])
+        vp = np.concatenate([v.rects_from_poses(*poses[:5]), v.rects_from_poses(*poses[5:])])
+        cp = np.concatenate([oracle.rects_from_poses(*poses[:5]), oracle.rects_from_poses(*poses[5:])])
+        assert 0.02 < (vp.view(np.uint32) != cp.view(np.uint32)).mean() < 0.2    # the vertices DO depend on it ...
+        pout, _ = v.sat_rect_pairs_pose(poses)
+        assert (pout != pref).sum() <= 2                                           # ... random pairs' booleans (almost) never
+        h = v.mc_pair(sc["robot_w"], sc["robot_h"], sc["pos"], sc["pose"], sc["std_dev"], 1234, 0, 0, 1_000_000)
+        assert abs(h - href) <= 5
