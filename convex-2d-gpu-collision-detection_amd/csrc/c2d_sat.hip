@@ -126,8 +126,14 @@ __global__ __launch_bounds__(kBlock) void sat_rect_aos_kernel(const float* __res
 
 // ---- rectangle pairs, pose format (10 planes, 41 B/pair) ------------------------------
 // Same lane mapping as the vertex kernel (VEC == 4: one float4 per plane, 4 pairs
-// per lane); both rectangles are rebuilt per pair (2 sincos + 2 x 16 ops), which
-// moves this format towards the VALU roof: ~400 VALU instructions per 41 bytes.
+// per lane); both rectangles are rebuilt per pair (2 sincos + 2 x 16 ops): 394 VALU
+// instructions per 41 bytes, which makes this format VALU-bound, not HBM-bound.  Measured
+// (profiles/r02_pose_probe.txt, tools/pose_probe.hip): under this kernel the shader clock settles near
+// 1.4 GHz (s_memtime against s_memrealtime), and 61.6e6 wave-instructions x 2 cycles / 1024 SIMDs at that
+// clock IS the 86 us the kernel takes.  A software-pipelined resident-wave form (next group's loads in
+// flight during the evaluation, 2 to 4 waves per SIMD) issues at the same rate and was 3-6 % slower
+// (89-91 us); SLP-packed v_pk_mul_f32 cuts the count to 321 per pair but costs double issue (96 us).
+// The bit-exact 8-axis evaluation fixes the instruction count, so this kernel is at its roof.
 C2D_DEV uint32_t pose_pair_collides(const float (&v)[10])
 {
     float r1[8], r2[8], s, c;
