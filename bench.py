@@ -321,15 +321,10 @@ def main() -> None:
 
     achieved_gbs = BYTES_PER_PAIR * n / (kernel_ms * 1e-3) / 1e9
     traffic, traffic_source = None, None
-    tpath = os.path.join(ROOT, "profiles", "sat_rect_verts_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            if int(tj.get("pairs", 0)) == n:
-                traffic = tj.get("hbm_bytes_per_launch")
-                traffic_source = "recorded, not measured in this run: %s (2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes)" % tj.get("source")
-        except Exception:
-            traffic = None
+    c = counts.get("sat_rect_verts.config2")
+    if c and n == c.get("pairs"):
+        traffic = c.get("hbm_bytes_per_launch")
+        traffic_source = "recorded, not measured in this run: %s (2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes)" % c.get("source")
     roofline = {"bound": "hbm", "kernel": "sat_rect_verts_kernel<4, 64>", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": BYTES_PER_PAIR * n, "kernel_ms": round(kernel_ms, 5),
@@ -364,7 +359,12 @@ def main() -> None:
             lane = n / (pms * 1e-3) * c["valu_instr_per_pair"] / 1e12
             pose_leg["valu_roofline"] = {"bound": "valu", "achieved": round(lane, 2), "peak": VALU_PEAK_TLANE, "unit": "T VALU lane-instr/s",
                                          "frac": round(lane / VALU_PEAK_TLANE, 4), "valu_instr_per_pair": c["valu_instr_per_pair"],
-                                         "instr_source": c.get("source")}
+                                         "instr_source": c.get("source"),
+                                         "note": "peak priced at the nominal 2.4 GHz; under this kernel s_memtime advances at ~1.4 ticks/ns "
+                                                 "(profiles/r02a_pose_probe.txt), at which 394 instr/pair x 2 cycles is the measured time: the kernel "
+                                                 "is VALU-bound at the clock the chip holds, not HBM-bound"}
+            pose_leg["roofline"]["traffic"] = c.get("hbm_bytes_per_launch")
+            pose_leg["roofline"]["traffic_source"] = "recorded, not measured in this run: %s" % c.get("source")
     del pose
 
     # ---- Monte-Carlo leg: config 3 --------------------------------------------------------

@@ -1,0 +1,33 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence of one round on the GPU box:  bash profiles/collect.sh <tag>   (run from the repo root)
+# Raw output goes to gpurun_out/<tag>/ (scratch); profiles/summarize.py + pmc_digest.py condense it into profiles/<tag>_*.
+# Counter passes are separate runs without any tracing option, as the pool requires; the program after `--` is python3 itself.
+set -e -o pipefail
+TAG=${1:?tag}
+R=$PWD
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+export TMPDIR=/tmp
+SMALL="--steps 20 --warmup 2 --prewarm-ms 0 --no-cpu-baseline --mc-reps 2 --poly-reps 3"
+cd /tmp
+echo "== un-profiled bench"; timeout -k 10 500 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
+echo "== kernel trace + stats"; timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
+echo "== pmc FETCH_SIZE"; timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py $SMALL --no-mc --scenes 0 > /dev/null 2> $O/pmc_fetch.err
+echo "== pmc WRITE_SIZE"; timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py $SMALL --no-mc --scenes 0 > /dev/null 2> $O/pmc_write.err
+echo "== pmc SQ"; timeout -k 10 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -- python3 $R/bench.py $SMALL > /dev/null 2> $O/pmc_sq.err
+echo "== pmc SQ LDS (polygon kernel)"; timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_lds -- python3 $R/bench.py $SMALL --no-mc --no-pose --scenes 0 > /dev/null 2> $O/pmc_lds.err
+echo "== adaptive-loop trace (reference-default batch)"; timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $O/scenes_trace -- python3 $R/convex-2d-gpu-collision-detection_amd/csrc/tools/scenes_trace.py run $O/scenes > $O/scenes_run.txt 2> $O/scenes.err
+cd $R
+echo "== pose probe, clock probe"; timeout -k 10 120 convex-2d-gpu-collision-detection_amd/csrc/tools/pose_probe > profiles/${TAG}_pose_probe.txt
+timeout -k 10 120 convex-2d-gpu-collision-detection_amd/csrc/tools/clock_probe > profiles/${TAG}_clock_probe_raw.txt
+python3 profiles/summarize.py $TAG $O/stats $O/pmc_fetch $O/pmc_write
+python3 profiles/pmc_digest.py $O/pmc_sq > profiles/${TAG}_pmc_sq.txt
+python3 profiles/pmc_digest.py $O/pmc_lds > profiles/${TAG}_pmc_lds.txt
+python3 convex-2d-gpu-collision-detection_amd/csrc/tools/scenes_trace.py digest $O/scenes_trace $O/scenes > profiles/${TAG}_scenes_trace.md
+cp $O/bench.json profiles/${TAG}_bench.json
+cp $O/bench_under_rocprof.json profiles/${TAG}_bench_under_rocprof.json
+mkdir -p $R/gpurun_out/${TAG}_profiles && cp profiles/${TAG}_* $R/gpurun_out/${TAG}_profiles/
+# the raw traces are large: keep only what the digests came from, compressed
+find $O -name "*.csv" -size +2M -exec gzip -f {} \;
+find $O -name "*.gz" -size +20M -delete
+echo "== done"

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 output (gpurun_out/prof/...) into the small summaries kept under profiles/.
 
-usage: python profiles/summarize.py <round-tag> <stats_dir> [<pmc_fetch_dir> <pmc_write_dir> [pairs]]
+usage: python profiles/summarize.py <round-tag> <stats_dir> [<pmc_fetch_dir> <pmc_write_dir>]
  - kernel stats: the --kernel-trace --stats CSV with kernel names cut to 90 characters
  - PMC: per-kernel mean FETCH_SIZE / WRITE_SIZE (KB, as rocprofv3 reports them) and the
    HBM bytes per launch after the gfx950 correction of MI355X_MICROARCH.md §HBM
@@ -47,13 +47,6 @@ def main():
             v["hbm_bytes_per_launch_corrected"] = 2 * fetch + write
             v["correction"] = "2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE reports half of streamed read bytes)"
         json.dump(res, open(os.path.join(here, f"{tag}_pmc_hbm.json"), "w"), indent=1)
-        if len(sys.argv) >= 6:
-            pairs = int(sys.argv[5])
-            for k, v in res.items():
-                if "sat_rect_verts_kernel<4" in k:
-                    json.dump({"pairs": pairs, "kernel": k, "hbm_bytes_per_launch": v["hbm_bytes_per_launch_corrected"],
-                               "algorithmic_bytes_per_launch": 65 * pairs, "source": f"profiles/{tag}_pmc_hbm.json"},
-                              open(os.path.join(here, "sat_rect_verts_traffic.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
