@@ -11,6 +11,10 @@
  *   Variance / StdDev         {x,y,theta,width,height}    utils.cu:86-89,106
  *   Pose                      {width,height,theta}        utils.cu:91-94
  *   PoseCPVarAndPoseIdx       {x,y,cp,var_idx,pose_idx}   utils.cu:96-99   (= one row of data_out/<k>.npy)
+ *   PoseCPVarAndPoseIdxIdx    {p, idx}                    utils.cu:100-104 (a row + its original position; the
+ *                             reference needs it to undo its compaction sort, compute_collision_probability.cu:337-344;
+ *                             c2d keeps scene i in slot i, so nothing here produces it — it is published for callers
+ *                             that carry the reference's host code over)
  *
  * All fields are IEEE-754 binary32; indices are stored *as float* exactly as
  * the reference does (utils.cu:82-83).  Plain C, usable from C, C++, HIP and
@@ -46,6 +50,11 @@ typedef struct Pose {
 typedef struct PoseCPVarAndPoseIdx {
     float x, y, cp, var_idx, pose_idx;
 } PoseCPVarAndPoseIdx;
+
+typedef struct PoseCPVarAndPoseIdxIdx {
+    PoseCPVarAndPoseIdx p;
+    int idx;
+} PoseCPVarAndPoseIdxIdx;
 
 /* A rectangle is a flat float[8]: x0,y0,x1,y1,x2,y2,x3,y3, counter-clockwise,
  * starting at (-w/2,-h/2) (reference utils.cu:119-130). */

@@ -46,7 +46,7 @@ def test_version_and_status_strings(pkg):
     lib = pkg.load_library()
     assert lib.c2d_version() == 1
     assert lib.c2d_status_string(0) == b"ok"
-    for st in (-1, -2, -3, -4, -5):
+    for st in (-1, -2, -3, -4, -5, -6):
         assert lib.c2d_status_string(st) not in (b"ok", b"unknown status")
     assert lib.c2d_status_string(-99) == b"unknown status"
 
@@ -92,7 +92,11 @@ def test_stream_is_rocrand_philox(tmp_path, oracle):
 def test_headers_are_plain_c(tmp_path):
     """include/c2d.h and include/utils.h are the FFI surface: they must compile as C11 and as C++17."""
     src = tmp_path / "t.c"
-    src.write_text('#include "c2d.h"\nint main(void){ float r[8]; create_rect(r, 2.f, 1.f); return sizeof(c2d_mc_scenes_args) > 0 ? 0 : 1; }\n')
+    src.write_text('#include "c2d.h"\nint main(void){ float r[8]; create_rect(r, 2.f, 1.f); '
+                   'return sizeof(c2d_mc_scenes_args) > 0 && sizeof(PoseCPVarAndPoseIdxIdx) == 24 && sizeof(PoseCPVarAndPoseIdx) == 20 ? 0 : 1; }\n')
     inc = "-I" + os.path.join(ROOT, "include")
     subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", inc, "-c", str(src), "-o", str(tmp_path / "t.o")], check=True)
     subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-pedantic", "-Werror", inc, "-x", "c++", "-c", str(src), "-o", str(tmp_path / "t2.o")], check=True)
+    # the struct sizes of utils.cu:74-104 (the program only uses header-inline code, so it links without libc2d)
+    subprocess.run(["gcc", "-std=c11", inc, str(src), "-o", str(tmp_path / "t")], check=True)
+    assert subprocess.run([str(tmp_path / "t")]).returncode == 0
