@@ -87,6 +87,15 @@ def test_stream_is_rocrand_philox(tmp_path, oracle):
         out = subprocess.run([str(exe), str(seed), str(scene), str(sample), "8"], check=True, capture_output=True, text=True).stdout
         ref = np.array([[int(v) for v in line.split()] for line in out.strip().splitlines()], np.uint32)
         assert np.array_equal(oracle.raw8(seed, scene, sample, 8), ref)
+    # "rocRAND replacing curand": the five normals of a sample are rocRAND's own rocrand_normal4 / rocrand_normal of the
+    # same state up to the rounding of the math functions (c2d fixes bit-reproducible log / sqrt / sincos forms and centres
+    # the uniform at (x + 1/2) / 2^32 where rocRAND uses (x + 1) / 2^32; glibc / OCML differ between host and device anyway)
+    out = subprocess.run([str(exe), "1234", "77", "1000", "4000", "normals"], check=True, capture_output=True, text=True).stdout
+    theirs = np.array([[float(v) for v in line.split()] for line in out.strip().splitlines()], np.float64)
+    ours = oracle.normals5(1234, 77, 1000, 4000).astype(np.float64)
+    assert theirs.shape == ours.shape == (4000, 5)
+    assert np.abs(ours - theirs).max() < 2e-5 and np.abs(ours - theirs).mean() < 2e-7
+    assert abs(theirs.std() - 1.0) < 0.02
 
 
 def test_headers_are_plain_c(tmp_path):
