@@ -330,6 +330,31 @@ def main() -> None:
                 "algorithmic_bytes_per_launch": BYTES_PER_PAIR * n, "kernel_ms": round(kernel_ms, 5),
                 "step_ms_distribution": step_ms}
 
+    # ---- same kernel arithmetic, bit-mask output (64.125 B/pair) ---------------------------------------------------
+    mask_leg = None
+    if not args.no_pose:
+        mwords = torch.zeros((n + 63) // 64, dtype=torch.int64, device=dev)
+        mcount = torch.zeros(1, dtype=torch.int64, device=dev)
+
+        def mask_step():
+            eng.sat_rect_pairs_verts_mask(plane_ptrs, n, mwords.data_ptr(), mcount.data_ptr(), stream=sh)
+
+        prewarm(mask_step)
+        me0, me1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        me0.record(stream)
+        for _ in range(args.steps):
+            mask_step()
+        me1.record(stream)
+        torch.cuda.synchronize()
+        mms = me0.elapsed_time(me1) / args.steps
+        mgbs = (64 * n + (n + 7) // 8) / (mms * 1e-3) / 1e9
+        mask_leg = {"metric": "sat_pair_tests_per_s (bit-mask output, per GPU)", "value": n / (mms * 1e-3), "kernel_ms": round(mms, 5),
+                    "bytes_per_pair": 64.125,
+                    "roofline": {"bound": "hbm", "kernel": "sat_rect_verts_mask4_kernel", "achieved": round(mgbs, 1), "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": round(mgbs / HBM_PEAK_GBS, 4), "traffic": None}}
+        del mwords
+
     # ---- secondary input format: poses (41 B/pair), reported separately ----------
     pose_leg = None
     if not args.no_pose:
@@ -551,7 +576,7 @@ def main() -> None:
                        "parallelism": f"pairs sharded over {world} GPU(s), one process per GPU, no data-path collective, one sum of the hit count per leg",
                        "reduce": reduce_impl,
                        "ranks_in_reduce": (cdist.world_size if cdist is not None else (dist.get_world_size() if use_dist else 1))},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "pose_format": pose_leg, "mc": mc, "scenes": scenes_leg, "poly": poly_leg,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "mask_output": mask_leg, "pose_format": pose_leg, "mc": mc, "scenes": scenes_leg, "poly": poly_leg,
             "device": eng.info()["name"],
         }
         sys.stdout.flush()

@@ -87,6 +87,7 @@ _SIGNATURES = {
     "c2d_stream_synchronize": (C.c_int, [C.c_void_p, C.c_void_p]),
     "c2d_rects_from_poses": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_size_t, C.POINTER(C.c_void_p), C.c_void_p]),
     "c2d_sat_rect_pairs_verts": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "c2d_sat_rect_pairs_verts_mask": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "c2d_sat_rect_pairs_aos": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "c2d_sat_rect_pairs_pose": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "c2d_sat_poly_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -335,6 +336,13 @@ class Engine:
     def sat_rect_pairs_aos(self, r1, r2, n: int, out, count=None, stream: int = 0):
         self._check(self.lib.c2d_sat_rect_pairs_aos(self.h, _ptr_of(r1), _ptr_of(r2), n, _ptr_of(out), _ptr_of(count),
                                                     C.c_void_p(stream)), "c2d_sat_rect_pairs_aos")
+
+    def sat_rect_pairs_verts_mask(self, planes: Sequence, n: int, mask, count=None, stream: int = 0):
+        if len(planes) != 16:
+            raise ValueError("need 16 vertex planes")
+        arr = (C.c_void_p * 16)(*[_ptr_of(p) for p in planes])
+        self._check(self.lib.c2d_sat_rect_pairs_verts_mask(self.h, arr, n, _ptr_of(mask), _ptr_of(count), C.c_void_p(stream)),
+                    "c2d_sat_rect_pairs_verts_mask")
 
     def sat_rect_pairs_pose(self, planes: Sequence, n: int, out, count=None, stream: int = 0):
         if len(planes) != 10:

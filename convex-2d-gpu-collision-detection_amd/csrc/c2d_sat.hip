@@ -69,6 +69,68 @@ __global__ __launch_bounds__(BLOCK) void sat_rect_verts_kernel(Planes16 P, size_
     if (d_count) wave_count_arrive(my_count, d_count, words);
 }
 
+// ---- rectangle pairs, vertex format, bit-mask output -------------------------------------------
+// For callers that only need the mask: one bit per pair (bit i & 63 of word i >> 6) instead of one byte, 64.125
+// instead of 65 bytes per pair.  Wide form: the same loads and lane mapping as above (lane = 4 consecutive pairs), a
+// wave covers 256 pairs = four 64-bit words; lane l holds bits 4(l & 15) .. +3 of word l >> 4, and an OR over each
+// 16-lane row assembles the word.  The plain form (one pair per lane, one ballot per wave) takes what is left.
+__global__ __launch_bounds__(64) void sat_rect_verts_mask4_kernel(Planes16 P, size_t n_groups, unsigned long long* __restrict__ mask,
+                                                                  unsigned long long* __restrict__ d_count,
+                                                                  unsigned long long* __restrict__ words)
+{
+    const uint32_t lane = threadIdx.x;
+    const size_t g = (size_t)blockIdx.x * 64 + lane;  // n_groups is a multiple of 64: every wave is full
+    f32x4 v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P.p[k]) + g);
+    uint32_t nib = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        float r1[8], r2[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            r1[k] = v[k][e];
+            r2[k] = v[8 + k][e];
+        }
+        nib |= (rect_collide(r1, r2) ? 1u : 0u) << e;
+    }
+    const uint32_t sh = 4u * (lane & 15u);
+    uint32_t lo = sh < 32u ? nib << sh : 0u, hi = sh >= 32u ? nib << (sh - 32u) : 0u;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+        lo |= (uint32_t)__shfl_xor((int)lo, off, 64);
+        hi |= (uint32_t)__shfl_xor((int)hi, off, 64);
+    }
+    if ((lane & 15u) == 0) __builtin_nontemporal_store(((unsigned long long)hi << 32) | lo, mask + ((size_t)blockIdx.x * 4 + (lane >> 4)));
+    if (d_count) wave_count_arrive((uint32_t)__popc(nib), d_count, words);
+}
+
+__global__ __launch_bounds__(kBlock) void sat_rect_verts_mask1_kernel(Planes16 P, size_t first, size_t n, unsigned long long* __restrict__ mask,
+                                                                      unsigned long long* __restrict__ d_count,
+                                                                      unsigned long long* __restrict__ words)
+{
+    // `first` is a multiple of 64 and every wave owns the 64 pairs of one word
+    uint32_t my_count = 0;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    const size_t n_round = (n + 63) / 64 * 64;
+    for (size_t i = first + (size_t)blockIdx.x * kBlock + threadIdx.x; i < n_round; i += stride) {
+        uint32_t c = 0;
+        if (i < n) {
+            float r1[8], r2[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                r1[k] = P.p[k][i];
+                r2[k] = P.p[8 + k][i];
+            }
+            c = rect_collide(r1, r2) ? 1u : 0u;
+        }
+        const unsigned long long b = __ballot(c != 0);
+        if ((threadIdx.x & 63) == 0) mask[i >> 6] = b;
+        my_count += c;
+    }
+    if (d_count) wave_count_arrive(my_count, d_count, words);
+}
+
 // ---- rectangle pairs, array-of-rectangles format ----------------------------------------
 // The reference's own argument layout, convex_collide(float* r1, float* r2) with flat
 // float[8] rectangles (utils.cu:159), batched: r1, r2 are f32[n][8].  A lane reads its
@@ -253,6 +315,43 @@ int c2d_sat_rect_pairs_verts(c2d_ctx* ctx, const float* const d_planes[16], size
         const int grid = grid_for(rest, kBlock, kMaxBlocks);
         hipLaunchKernelGGL((sat_rect_verts_kernel<1, kBlock>), dim3(grid), dim3(kBlock), 0, s, P, 4 * n4, rest, d_out, d_count,
                            ctx->d_count_words);
+        C2D_LAUNCH_CHECK(ctx);
+    }
+    workspace_release(ctx, s, d_count != nullptr);
+    return C2D_OK;
+}
+
+int c2d_sat_rect_pairs_verts_mask(c2d_ctx* ctx, const float* const d_planes[16], size_t n, unsigned long long* d_mask,
+                                  unsigned long long* d_count, c2d_stream stream)
+{
+    if (!ctx) return C2D_ERR_INVALID_ARG;
+    if (n == 0) return C2D_OK;
+    if (!d_planes || !d_mask) return fail_arg(ctx, "c2d_sat_rect_pairs_verts_mask: NULL argument");
+    if (!aligned_to(d_mask, 8)) return fail_arg(ctx, "c2d_sat_rect_pairs_verts_mask: the mask must be 8-byte aligned");
+    Planes16 P;
+    bool wide = true;
+    for (int k = 0; k < 16; k++) {
+        if (!d_planes[k]) return fail_arg(ctx, "c2d_sat_rect_pairs_verts_mask: NULL plane");
+        P.p[k] = d_planes[k];
+        wide = wide && aligned_to(d_planes[k], 16);
+    }
+    DeviceGuard g(ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    if (int rc = workspace_acquire(ctx, s, d_count != nullptr)) return rc;
+    size_t done = 0;
+    while (wide && n - done >= 256) {  // full waves of 256 pairs; more than kMaxBlocks of them go in several launches
+        size_t waves = (n - done) / 256;
+        if (waves > (size_t)kMaxBlocks) waves = (size_t)kMaxBlocks;
+        Planes16 Q;
+        for (int k = 0; k < 16; k++) Q.p[k] = P.p[k] + done;
+        hipLaunchKernelGGL(sat_rect_verts_mask4_kernel, dim3((unsigned)waves), dim3(64), 0, s, Q, waves * 64, d_mask + done / 64, d_count,
+                           ctx->d_count_words);
+        C2D_LAUNCH_CHECK(ctx);
+        done += waves * 256;
+    }
+    if (done < n) {
+        const int grid = grid_for(n - done, kBlock, kMaxBlocks);
+        hipLaunchKernelGGL(sat_rect_verts_mask1_kernel, dim3(grid), dim3(kBlock), 0, s, P, done, n, d_mask, d_count, ctx->d_count_words);
         C2D_LAUNCH_CHECK(ctx);
     }
     workspace_release(ctx, s, d_count != nullptr);

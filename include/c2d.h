@@ -131,6 +131,14 @@ int c2d_rects_from_poses(c2d_ctx* ctx, const float* d_cx, const float* d_cy, con
 int c2d_sat_rect_pairs_verts(c2d_ctx* ctx, const float* const d_planes[16], size_t n,
                              uint8_t* d_out, unsigned long long* d_count, c2d_stream stream);
 
+/* c2d_sat_rect_pairs_verts_mask: the same test with a bit mask as output, for callers that only
+ * need collide / no-collide: bit (i & 63) of d_mask[i >> 6] is the result of pair i (1 = collide);
+ * d_mask is a device u64[(n + 63) / 64], 8-byte aligned; the unused high bits of the last word are 0.
+ * 64.125 instead of 65 bytes of traffic per pair. */
+int c2d_sat_rect_pairs_verts_mask(c2d_ctx* ctx, const float* const d_planes[16], size_t n,
+                                  unsigned long long* d_mask, unsigned long long* d_count,
+                                  c2d_stream stream);
+
 /* c2d_sat_rect_pairs_aos: the same test on the reference's own argument layout,
  * convex_collide(float* r1, float* r2) (utils.cu:159) with flat float[8]
  * rectangles, batched: d_r1 and d_r2 are f32[n][8] (16-byte aligned), pair i is

@@ -66,6 +66,7 @@ def main():
     pout = torch.zeros(npoly, dtype=torch.uint8, device=dev)
     pcnt = torch.zeros(1, dtype=torch.int64, device=dev)
     pose_out = torch.zeros(n, dtype=torch.uint8, device=dev)
+    mask = torch.zeros((n + 63) // 64, dtype=torch.int64, device=dev)
 
     g = torch.cuda.CUDAGraph()
     side = torch.cuda.Stream(device=dev)
@@ -78,6 +79,7 @@ def main():
         mc_scenes_async(sh)
         eng.sat_poly_pairs(pvx.data_ptr(), pvy.data_ptr(), pk.data_ptr(), npoly, pout.data_ptr(), pcnt.data_ptr(), stream=sh)
         eng.sat_rect_pairs_pose([row(pose, k) for k in range(10)], n, pose_out.data_ptr(), None, stream=sh)
+        eng.sat_rect_pairs_verts_mask([row(planes, k) for k in range(16)], n, mask.data_ptr(), None, stream=sh)
     torch.cuda.synchronize()
     assert int(cnt.item()) == 0 and not out.any(), "capture must not execute anything"
     for _ in range(3):
@@ -94,6 +96,7 @@ def main():
     ref_poly, ref_pcnt = oracle.sat_poly_pairs(pvx_h, pvy_h, pk_h)
     assert np.array_equal(pout.cpu().numpy(), ref_poly) and int(pcnt.item()) == 3 * ref_pcnt
     assert np.array_equal(pose_out.cpu().numpy(), ref_out)
+    assert np.array_equal(np.unpackbits(mask.cpu().numpy().view(np.uint8), bitorder="little")[:n], ref_out)
     eng.check_async()
 
 

@@ -187,6 +187,30 @@ def test_full_size_properties_1e7(eng, wl):
         a.free()
 
 
+@pytest.mark.parametrize("n,offset", [(1, 0), (63, 0), (64, 0), (65, 0), (255, 0), (256, 0), (257, 0), (1000, 0), (100_003, 0),
+                                      (1_000_003, 0), (5000, 1), (70_001, 3)])
+def test_bit_mask_output(eng, oracle, wl, n, offset):
+    """c2d_sat_rect_pairs_verts_mask: one bit per pair, little-endian within 64-bit words, unused high bits zero;
+    offset != 0 shifts the planes off their 16-byte alignment (one pair per lane path)."""
+    poses = wl.random_obb_pose_planes(n, seed=31 + n, extent=3.0)
+    planes = np.concatenate([oracle.rects_from_poses(*poses[:5]), oracle.rects_from_poses(*poses[5:])])
+    ref, ref_cnt = oracle.sat_rect_pairs_verts(planes)
+    host = np.zeros((16, n + 8), np.float32)
+    host[:, offset:offset + n] = planes
+    d = eng.to_device(host)
+    words = (n + 63) // 64
+    d_mask = eng.to_device(np.full(words + 2, 0xFFFFFFFFFFFFFFFF, np.uint64))   # poisoned: every word must be written
+    d_cnt = eng.zeros(1, np.uint64)
+    eng.sat_rect_pairs_verts_mask([d.row(k) + 4 * offset for k in range(16)], n, d_mask, d_cnt)
+    mask = d_mask.get()
+    assert (mask[words:] == 0xFFFFFFFFFFFFFFFF).all()                            # nothing written past the mask
+    bits = np.unpackbits(mask[:words].view(np.uint8), bitorder="little")
+    assert np.array_equal(bits[:n], ref) and not bits[n:].any()
+    assert int(d_cnt.get()[0]) == ref_cnt
+    for a in (d, d_mask, d_cnt):
+        a.free()
+
+
 # ---- polygons ---------------------------------------------------------------------------------
 
 def run_poly(eng, vx, vy, k):
