@@ -79,6 +79,8 @@ _SIGNATURES = {
     "c2d_ctx_check_async": (C.c_int, [C.c_void_p]),
     "c2d_malloc": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]),
     "c2d_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "c2d_malloc_host": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]),
+    "c2d_free_host": (C.c_int, [C.c_void_p, C.c_void_p]),
     "c2d_memset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
     "c2d_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "c2d_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

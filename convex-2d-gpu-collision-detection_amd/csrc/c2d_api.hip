@@ -114,6 +114,27 @@ int c2d_free(c2d_ctx* ctx, void* d_ptr)
     return C2D_OK;
 }
 
+int c2d_malloc_host(c2d_ctx* ctx, void** h_ptr, size_t bytes)
+{
+    if (!ctx || !h_ptr) return C2D_ERR_INVALID_ARG;
+    *h_ptr = nullptr;
+    if (bytes == 0) return C2D_OK;
+    c2d::DeviceGuard g(ctx->device);
+    hipError_t e = hipHostMalloc(h_ptr, bytes, hipHostMallocDefault);
+    if (e == hipErrorOutOfMemory) { ctx->last_error = "hipHostMalloc: out of memory"; return C2D_ERR_NOMEM; }
+    if (e != hipSuccess) return c2d::fail_hip(ctx, e, "hipHostMalloc", __FILE__, __LINE__);
+    return C2D_OK;
+}
+
+int c2d_free_host(c2d_ctx* ctx, void* h_ptr)
+{
+    if (!ctx) return C2D_ERR_INVALID_ARG;
+    if (!h_ptr) return C2D_OK;
+    c2d::DeviceGuard g(ctx->device);
+    C2D_HIP(ctx, hipHostFree(h_ptr));
+    return C2D_OK;
+}
+
 int c2d_memset(c2d_ctx* ctx, void* d_ptr, int value, size_t bytes, c2d_stream stream)
 {
     if (!ctx || (!d_ptr && bytes)) return C2D_ERR_INVALID_ARG;

@@ -171,10 +171,10 @@ int main(int argc, char* argv[])
     if (num_poses == 0 || num_variances == 0) { std::cerr << "error: empty pose / variance table\n"; return EXIT_FAILURE; }
     std::vector<StdDev> std_devs = std_devs_from_variances(variances.data);
 
-    c2d_ctx* ctx = nullptr;
-    C2D_CALL(ctx, c2d_ctx_create(shard.device, &ctx));
-    c2d_stream stream = nullptr;
-    C2D_CALL(ctx, c2d_stream_create(ctx, &stream));
+    BatchSlot slots[2];
+    for (auto& sl : slots) C2D_CALL(sl.ctx, sl.open(shard.device, N));
+    c2d_ctx* ctx = slots[0].ctx;          // owner of the tables and of the aggregation link
+    c2d_stream stream = slots[0].stream;
     DistLink link;
     C2D_CALL(ctx, link.open(ctx, shard));
     if (link.active()) {  // rank 0's view of the output directory is everyone's
@@ -182,19 +182,13 @@ int main(int argc, char* argv[])
         C2D_CALL(ctx, link.broadcast(w, 1, stream));
         start_batch_count = static_cast<int>(w[0]);
     }
-    void *d_poses = nullptr, *d_sd = nullptr, *d_scenes = nullptr, *d_hits = nullptr, *d_used = nullptr, *d_rows = nullptr;
+    void *d_poses = nullptr, *d_sd = nullptr;
     C2D_CALL(ctx, c2d_malloc(ctx, &d_poses, poses.data.size() * sizeof(float)));
     C2D_CALL(ctx, c2d_malloc(ctx, &d_sd, std_devs.size() * sizeof(StdDev)));
-    C2D_CALL(ctx, c2d_malloc(ctx, &d_scenes, N * sizeof(PositionWithVarAndPoseIdx)));
-    C2D_CALL(ctx, c2d_malloc(ctx, &d_hits, N * sizeof(uint32_t)));
-    C2D_CALL(ctx, c2d_malloc(ctx, &d_used, N * sizeof(uint32_t)));
-    C2D_CALL(ctx, c2d_malloc(ctx, &d_rows, N * sizeof(PoseCPVarAndPoseIdx)));
     C2D_CALL(ctx, c2d_memcpy_h2d(ctx, d_poses, poses.data.data(), poses.data.size() * sizeof(float), stream));
     C2D_CALL(ctx, c2d_memcpy_h2d(ctx, d_sd, std_devs.data(), std_devs.size() * sizeof(StdDev), stream));
     C2D_CALL(ctx, c2d_stream_synchronize(ctx, stream));
 
-    std::vector<PoseCPVarAndPoseIdx> dataset(N);
-    std::vector<uint32_t> hits(N);
     const auto begin = std::chrono::steady_clock::now();
     if (chatty) {
         std::cout << "Total number of configurations: " << static_cast<long long>(N) * num_batches << std::endl;
@@ -203,50 +197,43 @@ int main(int argc, char* argv[])
     int counter = 0;
     RunStats stats;
     if (chatty) std::printf("batches generated: %i/%i\n", counter, num_batches);
-    for (int batch_index = shard.rank; batch_index < num_batches; batch_index += shard.world) {
-        npy::Array batch;
-        try {
-            batch = npy::load_f32(a.data_in + "/" + std::to_string(batch_index) + ".npy");  // :261
-        } catch (const std::exception& e) {
-            std::cerr << "error: " << e.what() << "\n";
-            return EXIT_FAILURE;
-        }
-        if (batch.data.size() != N * 4) {
-            std::cerr << "error: " << batch_index << ".npy does not hold " << N << " rows of 4\n";
-            return EXIT_FAILURE;
-        }
+
+    // read + upload + adaptive loop + downloads of one batch, enqueued without waiting for the GPU
+    auto enqueue = [&](BatchSlot& sl, int batch_index) -> int {
+        npy::Array batch = npy::load_f32(a.data_in + "/" + std::to_string(batch_index) + ".npy");  // :261
+        if (batch.data.size() != N * 4) throw std::runtime_error(std::to_string(batch_index) + ".npy does not hold " + std::to_string(N) + " rows of 4");
+        std::copy(batch.data.begin(), batch.data.end(), sl.input);  // page-locked: the upload below does not wait
         // the [N,4] rows are PositionWithVarAndPoseIdx records: upload them as they are (:262-274)
-        C2D_CALL(ctx, c2d_memcpy_h2d(ctx, d_scenes, batch.data.data(), N * sizeof(PositionWithVarAndPoseIdx), stream));
+        int st = c2d_memcpy_h2d(sl.ctx, sl.d_scenes, sl.input, N * sizeof(PositionWithVarAndPoseIdx), sl.stream);
+        if (st != C2D_OK) return st;
         c2d_mc_scenes_args m{};
         m.d_poses = static_cast<const Pose*>(d_poses); m.num_poses = num_poses;
         m.d_std_devs = static_cast<const StdDev*>(d_sd); m.num_std_devs = num_variances;
-        m.d_scenes = static_cast<const PositionWithVarAndPoseIdx*>(d_scenes); m.n_scenes = N;
+        m.d_scenes = static_cast<const PositionWithVarAndPoseIdx*>(sl.d_scenes); m.n_scenes = N;
         m.robot_w = a.robot_width; m.robot_h = a.robot_height;
         m.accuracy_bins = accuracy_bins.data.data(); m.bin_accuracy = bin_accuracy.data.data();
         m.n_accuracy_bins = static_cast<uint32_t>(accuracy_bins.data.size());
         m.max_samples = static_cast<uint32_t>(a.max_samples);
         m.seed = a.seed;
         m.scene_id_base = (static_cast<uint64_t>(start_batch_count) + batch_index) * N;
-        m.d_hits = static_cast<uint32_t*>(d_hits); m.d_n_used = static_cast<uint32_t*>(d_used);
-        m.d_rows = static_cast<PoseCPVarAndPoseIdx*>(d_rows);
-        uint64_t total = 0;
-        m.total_samples = &total;
-        C2D_CALL(ctx, c2d_mc_scenes(ctx, &m, stream));  // adaptive loop, :276-332
-        C2D_CALL(ctx, c2d_memcpy_d2h(ctx, dataset.data(), d_rows, N * sizeof(PoseCPVarAndPoseIdx), stream));
-        C2D_CALL(ctx, c2d_memcpy_d2h(ctx, hits.data(), d_hits, N * sizeof(uint32_t), stream));
-        C2D_CALL(ctx, c2d_stream_synchronize(ctx, stream));
-        stats.samples += total;
+        m.d_hits = static_cast<uint32_t*>(sl.d_hits); m.d_n_used = static_cast<uint32_t*>(sl.d_used);
+        m.d_rows = static_cast<PoseCPVarAndPoseIdx*>(sl.d_rows);
+        st = c2d_mc_scenes(sl.ctx, &m, sl.stream);  // adaptive loop, :276-332 (no host output requested: asynchronous)
+        if (st == C2D_OK) st = sl.download();
+        sl.batch_index = batch_index;
+        return st;
+    };
+    auto finish = [&](BatchSlot& sl) -> int {
+        int st = c2d_stream_synchronize(sl.ctx, sl.stream);
+        if (st != C2D_OK) return st;
         stats.scenes += N;
-        for (uint32_t h : hits) stats.hits += h;
-        for (const auto& r : dataset) stats.add_cp(r.cp);
-        if (a.shuffle) std::shuffle(dataset.begin(), dataset.end(), std::default_random_engine(0));  // :346-349
-        try {
-            npy::save_f32(a.data_out + "/" + std::to_string(start_batch_count + batch_index) + ".npy", {N, 5},
-                          reinterpret_cast<const float*>(dataset.data()));  // :353-355
-        } catch (const std::exception& e) {
-            std::cerr << "error: " << e.what() << "\n";
-            return EXIT_FAILURE;
-        }
+        for (size_t i = 0; i < N; i++) stats.samples += sl.used[i];
+        for (size_t i = 0; i < N; i++) stats.hits += sl.hits[i];
+        for (size_t i = 0; i < N; i++) stats.add_cp(sl.dataset[i].cp);
+        if (a.shuffle) std::shuffle(sl.dataset, sl.dataset + N, std::default_random_engine(0));  // :346-349
+        npy::save_f32(a.data_out + "/" + std::to_string(start_batch_count + sl.batch_index) + ".npy", {N, 5},
+                      reinterpret_cast<const float*>(sl.dataset));  // :353-355
+        sl.batch_index = -1;
         const auto now = std::chrono::steady_clock::now();
         ++counter;
         if (chatty) {
@@ -255,6 +242,20 @@ int main(int argc, char* argv[])
                         static_cast<int>(std::chrono::duration_cast<std::chrono::minutes>(now - begin).count()));
             std::fflush(stdout);
         }
+        return C2D_OK;
+    };
+    try {
+        int turn = 0;
+        for (int batch_index = shard.rank; batch_index < num_batches; batch_index += shard.world, turn ^= 1) {
+            BatchSlot& sl = slots[turn];
+            if (sl.batch_index >= 0) C2D_CALL(sl.ctx, finish(sl));   // the batch enqueued two turns ago
+            C2D_CALL(sl.ctx, enqueue(sl, batch_index));
+        }
+        for (int k = 0; k < 2; k++, turn ^= 1)                       // drain in submission order
+            if (slots[turn].batch_index >= 0) C2D_CALL(slots[turn].ctx, finish(slots[turn]));
+    } catch (const std::exception& e) {
+        std::cerr << "error: " << e.what() << "\n";
+        return EXIT_FAILURE;
     }
     if (chatty) std::cout << std::endl;
     const auto end = std::chrono::steady_clock::now();
@@ -264,10 +265,9 @@ int main(int argc, char* argv[])
         std::cout << "Elapsed time: " << std::chrono::duration_cast<std::chrono::minutes>(end - begin).count() << " [min]" << std::endl;
     }
     C2D_CALL(ctx, print_json_summary("compute_collision_probability", shard, stats, counter, &link, stream));
-    for (void* ptr : {d_poses, d_sd, d_scenes, d_hits, d_used, d_rows}) c2d_free(ctx, ptr);
+    for (void* ptr : {d_poses, d_sd}) c2d_free(ctx, ptr);
     link.close();
-    c2d_stream_destroy(ctx, stream);
-    c2d_ctx_destroy(ctx);
+    for (auto& sl : slots) sl.close();
     if (chatty) std::cout << "Done." << std::endl;
     return 0;
 }

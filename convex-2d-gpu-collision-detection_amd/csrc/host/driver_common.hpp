@@ -146,6 +146,55 @@ struct DistLink {
     }
 };
 
+// Two batches in flight per rank.  A batch is: scenes on the device (sampled there, or uploaded), the adaptive loop,
+// the download of its rows / hit counts / sample counts.  All of it is asynchronous on the slot's stream, so while the
+// GPU works on batch k + 1 the host finishes batch k (statistics, shuffle, .npy file) — the reference does these
+// strictly one after the other (compute_collision_probability.cu:259-358).  Each slot has its own c2d_ctx (a ctx owns
+// one workspace) and its own stream; the pose / std_dev tables are shared device buffers.
+struct BatchSlot {
+    c2d_ctx* ctx = nullptr;
+    c2d_stream stream = nullptr;
+    void *d_scenes = nullptr, *d_hits = nullptr, *d_used = nullptr, *d_rows = nullptr;
+    // page-locked host buffers, so that the copies do not hold the host thread
+    PoseCPVarAndPoseIdx* dataset = nullptr;
+    uint32_t *hits = nullptr, *used = nullptr;
+    float* input = nullptr;     // compute_collision_probability: the [n,4] rows being uploaded
+    size_t n = 0;
+    int batch_index = -1;       // -1: idle
+    int open(int device, size_t n_rows)
+    {
+        n = n_rows;
+        int st = c2d_ctx_create(device, &ctx);
+        if (st == C2D_OK) st = c2d_stream_create(ctx, &stream);
+        if (st == C2D_OK) st = c2d_malloc(ctx, &d_scenes, n * sizeof(PositionWithVarAndPoseIdx));
+        if (st == C2D_OK) st = c2d_malloc(ctx, &d_hits, n * sizeof(uint32_t));
+        if (st == C2D_OK) st = c2d_malloc(ctx, &d_used, n * sizeof(uint32_t));
+        if (st == C2D_OK) st = c2d_malloc(ctx, &d_rows, n * sizeof(PoseCPVarAndPoseIdx));
+        if (st == C2D_OK) st = c2d_malloc_host(ctx, reinterpret_cast<void**>(&dataset), n * sizeof(PoseCPVarAndPoseIdx));
+        if (st == C2D_OK) st = c2d_malloc_host(ctx, reinterpret_cast<void**>(&hits), n * sizeof(uint32_t));
+        if (st == C2D_OK) st = c2d_malloc_host(ctx, reinterpret_cast<void**>(&used), n * sizeof(uint32_t));
+        if (st == C2D_OK) st = c2d_malloc_host(ctx, reinterpret_cast<void**>(&input), n * sizeof(PositionWithVarAndPoseIdx));
+        return st;
+    }
+    // enqueue the downloads of a finished adaptive loop
+    int download()
+    {
+        int st = c2d_memcpy_d2h(ctx, dataset, d_rows, n * sizeof(PoseCPVarAndPoseIdx), stream);
+        if (st == C2D_OK) st = c2d_memcpy_d2h(ctx, hits, d_hits, n * sizeof(uint32_t), stream);
+        if (st == C2D_OK) st = c2d_memcpy_d2h(ctx, used, d_used, n * sizeof(uint32_t), stream);
+        return st;
+    }
+    void close()
+    {
+        if (!ctx) return;
+        for (void* ptr : {d_scenes, d_hits, d_used, d_rows}) c2d_free(ctx, ptr);
+        for (void* ptr : {static_cast<void*>(dataset), static_cast<void*>(hits), static_cast<void*>(used), static_cast<void*>(input)}) c2d_free_host(ctx, ptr);
+        c2d_stream_destroy(ctx, stream);
+        c2d_ctx_destroy(ctx);
+        ctx = nullptr;
+    }
+};
+
 inline std::vector<StdDev> std_devs_from_variances(const std::vector<float>& var_flat)
 {
     // element-wise sqrt (generate_dataset.cu:309-317, compute_collision_probability.cu:188-194)

@@ -182,10 +182,11 @@ int main(int argc, char* argv[])
         std::cout << "num variances: " << a.num_variances << std::endl;
     }
 
-    c2d_ctx* ctx = nullptr;
-    C2D_CALL(ctx, c2d_ctx_create(shard.device, &ctx));
-    c2d_stream stream = nullptr;
-    C2D_CALL(ctx, c2d_stream_create(ctx, &stream));
+    const size_t B = static_cast<size_t>(a.batch_size);
+    BatchSlot slots[2];
+    for (auto& sl : slots) C2D_CALL(sl.ctx, sl.open(shard.device, B));
+    c2d_ctx* ctx = slots[0].ctx;          // owner of the tables and of the aggregation link
+    c2d_stream stream = slots[0].stream;
     DistLink link;
     C2D_CALL(ctx, link.open(ctx, shard));
     if (link.active()) {  // rank 0's seed is everyone's
@@ -194,20 +195,13 @@ int main(int argc, char* argv[])
         a.seed = w[0];
     }
     if (chatty) std::cout << "seed: " << a.seed << std::endl;
-    const size_t B = static_cast<size_t>(a.batch_size);
-    void *d_poses = nullptr, *d_sd = nullptr, *d_scenes = nullptr, *d_hits = nullptr, *d_used = nullptr, *d_rows = nullptr;
+    void *d_poses = nullptr, *d_sd = nullptr;
     C2D_CALL(ctx, c2d_malloc(ctx, &d_poses, poses.size() * sizeof(float)));
     C2D_CALL(ctx, c2d_malloc(ctx, &d_sd, std_devs.size() * sizeof(StdDev)));
-    C2D_CALL(ctx, c2d_malloc(ctx, &d_scenes, B * sizeof(PositionWithVarAndPoseIdx)));
-    C2D_CALL(ctx, c2d_malloc(ctx, &d_hits, B * sizeof(uint32_t)));
-    C2D_CALL(ctx, c2d_malloc(ctx, &d_used, B * sizeof(uint32_t)));
-    C2D_CALL(ctx, c2d_malloc(ctx, &d_rows, B * sizeof(PoseCPVarAndPoseIdx)));
     C2D_CALL(ctx, c2d_memcpy_h2d(ctx, d_poses, poses.data(), poses.size() * sizeof(float), stream));
     C2D_CALL(ctx, c2d_memcpy_h2d(ctx, d_sd, std_devs.data(), std_devs.size() * sizeof(StdDev), stream));
     C2D_CALL(ctx, c2d_stream_synchronize(ctx, stream));
 
-    std::vector<PoseCPVarAndPoseIdx> dataset(B);
-    std::vector<uint32_t> hits(B);
     const auto begin = std::chrono::steady_clock::now();
     if (chatty) {
         std::cout << "Total number of configurations: " << static_cast<long long>(a.batch_size) * a.num_batches << std::endl;
@@ -216,41 +210,43 @@ int main(int argc, char* argv[])
     int counter = 0;
     RunStats stats;
     if (chatty) std::printf("batches generated: %i/%i", counter, a.num_batches);
-    for (int batch_index = shard.rank; batch_index < a.num_batches; batch_index += shard.world) {
+
+    // everything of one batch that runs on the GPU, enqueued without waiting
+    auto enqueue = [&](BatchSlot& sl, int batch_index) -> int {
         const uint64_t scene_base = (static_cast<uint64_t>(a.start_batch_count) + batch_index) * B;
         // iteration == 0 branch of the reference kernel: draw the scenes (:207-219)
-        C2D_CALL(ctx, c2d_sample_scenes(ctx, static_cast<const Pose*>(d_poses), a.num_poses, static_cast<const StdDev*>(d_sd),
-                                        a.num_variances, a.robot_width, a.robot_height, a.spread, a.seed, scene_base, B,
-                                        static_cast<PositionWithVarAndPoseIdx*>(d_scenes), stream));
+        int st = c2d_sample_scenes(sl.ctx, static_cast<const Pose*>(d_poses), a.num_poses, static_cast<const StdDev*>(d_sd),
+                                   a.num_variances, a.robot_width, a.robot_height, a.spread, a.seed, scene_base, B,
+                                   static_cast<PositionWithVarAndPoseIdx*>(sl.d_scenes), sl.stream);
+        if (st != C2D_OK) return st;
         c2d_mc_scenes_args m{};
         m.d_poses = static_cast<const Pose*>(d_poses); m.num_poses = a.num_poses;
         m.d_std_devs = static_cast<const StdDev*>(d_sd); m.num_std_devs = a.num_variances;
-        m.d_scenes = static_cast<const PositionWithVarAndPoseIdx*>(d_scenes); m.n_scenes = B;
+        m.d_scenes = static_cast<const PositionWithVarAndPoseIdx*>(sl.d_scenes); m.n_scenes = B;
         m.robot_w = a.robot_width; m.robot_h = a.robot_height;
         m.accuracy_bins = a.accuracy_bins.data(); m.bin_accuracy = a.bin_accuracy.data();
         m.n_accuracy_bins = static_cast<uint32_t>(a.accuracy_bins.size());
         m.max_samples = static_cast<uint32_t>(a.max_samples);
         m.seed = a.seed; m.scene_id_base = scene_base;
-        m.d_hits = static_cast<uint32_t*>(d_hits); m.d_n_used = static_cast<uint32_t*>(d_used);
-        m.d_rows = static_cast<PoseCPVarAndPoseIdx*>(d_rows);
-        uint64_t total = 0;
-        m.total_samples = &total;
-        C2D_CALL(ctx, c2d_mc_scenes(ctx, &m, stream));  // adaptive loop, :425-479
-        C2D_CALL(ctx, c2d_memcpy_d2h(ctx, dataset.data(), d_rows, B * sizeof(PoseCPVarAndPoseIdx), stream));
-        C2D_CALL(ctx, c2d_memcpy_d2h(ctx, hits.data(), d_hits, B * sizeof(uint32_t), stream));
-        C2D_CALL(ctx, c2d_stream_synchronize(ctx, stream));
-        stats.samples += total;
+        m.d_hits = static_cast<uint32_t*>(sl.d_hits); m.d_n_used = static_cast<uint32_t*>(sl.d_used);
+        m.d_rows = static_cast<PoseCPVarAndPoseIdx*>(sl.d_rows);
+        st = c2d_mc_scenes(sl.ctx, &m, sl.stream);  // adaptive loop, :425-479 (no host output requested: asynchronous)
+        if (st == C2D_OK) st = sl.download();
+        sl.batch_index = batch_index;
+        return st;
+    };
+    // the host side of a batch: wait for its stream, statistics, shuffle, file
+    auto finish = [&](BatchSlot& sl) -> int {
+        int st = c2d_stream_synchronize(sl.ctx, sl.stream);
+        if (st != C2D_OK) return st;
         stats.scenes += B;
-        for (uint32_t h : hits) stats.hits += h;
-        for (const auto& r : dataset) stats.add_cp(r.cp);
-        std::shuffle(dataset.begin(), dataset.end(), std::default_random_engine(0));  // :496
-        try {
-            npy::save_f32(data_dir + "/" + std::to_string(a.start_batch_count + batch_index) + ".npy", {B, 5},
-                          reinterpret_cast<const float*>(dataset.data()));  // :499-500
-        } catch (const std::exception& e) {
-            std::cerr << "\nerror: " << e.what() << "\n";
-            return EXIT_FAILURE;
-        }
+        for (size_t i = 0; i < B; i++) stats.samples += sl.used[i];
+        for (size_t i = 0; i < B; i++) stats.hits += sl.hits[i];
+        for (size_t i = 0; i < B; i++) stats.add_cp(sl.dataset[i].cp);
+        std::shuffle(sl.dataset, sl.dataset + B, std::default_random_engine(0));  // :496
+        npy::save_f32(data_dir + "/" + std::to_string(a.start_batch_count + sl.batch_index) + ".npy", {B, 5},
+                      reinterpret_cast<const float*>(sl.dataset));  // :499-500
+        sl.batch_index = -1;
         const auto now = std::chrono::steady_clock::now();
         ++counter;
         if (chatty) {
@@ -259,6 +255,20 @@ int main(int argc, char* argv[])
                         a.num_batches, static_cast<int>(std::chrono::duration_cast<std::chrono::minutes>(now - begin).count()));
             std::fflush(stdout);
         }
+        return C2D_OK;
+    };
+    try {
+        int turn = 0;
+        for (int batch_index = shard.rank; batch_index < a.num_batches; batch_index += shard.world, turn ^= 1) {
+            BatchSlot& sl = slots[turn];
+            if (sl.batch_index >= 0) C2D_CALL(sl.ctx, finish(sl));   // the batch enqueued two turns ago
+            C2D_CALL(sl.ctx, enqueue(sl, batch_index));
+        }
+        for (int k = 0; k < 2; k++, turn ^= 1)                       // drain in submission order
+            if (slots[turn].batch_index >= 0) C2D_CALL(slots[turn].ctx, finish(slots[turn]));
+    } catch (const std::exception& e) {
+        std::cerr << "\nerror: " << e.what() << "\n";
+        return EXIT_FAILURE;
     }
     if (chatty) std::cout << std::endl;
     const auto end = std::chrono::steady_clock::now();
@@ -268,10 +278,9 @@ int main(int argc, char* argv[])
         std::cout << "Elapsed time: " << std::chrono::duration_cast<std::chrono::minutes>(end - begin).count() << " [min]" << std::endl;
     }
     C2D_CALL(ctx, print_json_summary("generate_dataset", shard, stats, counter, &link, stream));
-    for (void* ptr : {d_poses, d_sd, d_scenes, d_hits, d_used, d_rows}) c2d_free(ctx, ptr);
+    for (void* ptr : {d_poses, d_sd}) c2d_free(ctx, ptr);
     link.close();
-    c2d_stream_destroy(ctx, stream);
-    c2d_ctx_destroy(ctx);
+    for (auto& sl : slots) sl.close();
     if (chatty) std::cout << "Done." << std::endl;
     return 0;
 }

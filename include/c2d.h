@@ -95,6 +95,11 @@ int c2d_ctx_check_async(c2d_ctx* ctx);
  * on `stream`; call c2d_stream_synchronize before touching the host buffer. */
 int c2d_malloc(c2d_ctx* ctx, void** d_ptr, size_t bytes);
 int c2d_free(c2d_ctx* ctx, void* d_ptr);
+/* Page-locked host memory: copies to / from it really are asynchronous (a copy that involves pageable
+ * memory is staged by the runtime and may hold the calling thread until it is done), which is what lets a
+ * driver overlap the host side of one batch with the GPU side of the next (csrc/host/driver_common.hpp). */
+int c2d_malloc_host(c2d_ctx* ctx, void** h_ptr, size_t bytes);
+int c2d_free_host(c2d_ctx* ctx, void* h_ptr);
 int c2d_memset(c2d_ctx* ctx, void* d_ptr, int value, size_t bytes, c2d_stream stream);
 int c2d_memcpy_h2d(c2d_ctx* ctx, void* d_dst, const void* h_src, size_t bytes, c2d_stream stream);
 int c2d_memcpy_d2h(c2d_ctx* ctx, void* h_dst, const void* d_src, size_t bytes, c2d_stream stream);
