@@ -318,7 +318,8 @@ struct AdaptiveState {
 
 struct ScheduleArgs {
     uint32_t small_batch, large_batch, switch_at, max_samples;
-    uint32_t want_waves;   // waves that fill the chip (CUs x 32)
+    uint32_t want_waves;   // work items wanted per step (see c2d_mc_scenes)
+    uint32_t min_chunk;    // smallest sample range worth a work item
 };
 
 C2D_DEV uint32_t batch_of(const ScheduleArgs& S, uint32_t n_samples)
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(kMcBlock) void mc_scenes_advance_kernel(ScenesArgs 
     const uint32_t* active = A.state->identity ? nullptr : A.lists[A.state->list_sel];
     // split a scene's batch over several waves when few scenes are left, so that the
     // tail of the adaptive loop still fills the chip
-    const uint32_t max_split = (n_batch + 63) / 64;
+    const uint32_t max_split = (n_batch + A.sched.min_chunk - 1) / A.sched.min_chunk;
     uint32_t wps = (A.sched.want_waves + n_active - 1) / n_active;
     wps = wps < 1 ? 1 : (wps > max_split ? max_split : wps);
     uint32_t chunk = (n_batch + wps - 1) / wps;
@@ -673,7 +674,12 @@ int c2d_mc_scenes(c2d_ctx* ctx, const c2d_mc_scenes_args* a, c2d_stream stream)
         return fail_arg(ctx, "c2d_mc_scenes: max_samples out of range");
     S.max_samples = a->max_samples;
     const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
-    S.want_waves = cus * 32;
+    // Work items of a step = active scenes x chunks per scene.  The chip holds 5 waves per SIMD of this kernel (5120);
+    // items cost between ~100 and ~430 instructions per sample depending on the scene, so the step only balances when
+    // there are many more items than resident waves: CUs x 512 items of at least 1024 samples.  Reference-default batch
+    // (1e5 scenes, 58 steps): 74.9 ms with CUs x 32 items, 67.8 / 63.6 / 61.2 ms with x 64 / x 128 / x 512.
+    S.want_waves = cus * 512;
+    S.min_chunk = 1024;
     // number of schedule steps until n_samples >= max_samples (ccp.cu:281-287)
     uint32_t steps = 0;
     for (uint64_t ns = 0; ns < a->max_samples; steps++) ns += ns < S.switch_at ? S.small_batch : S.large_batch;
