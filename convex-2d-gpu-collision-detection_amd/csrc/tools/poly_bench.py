@@ -2,7 +2,8 @@
 """Developer tool: time c2d_sat_poly_pairs on the BASELINE config-5 workload (HIP events on the
 kernel's stream) and check a sample against the CPU oracle.  TEST INFRASTRUCTURE (uses oracle/).
 
-usage: poly_bench.py [pairs] [reps] [kmin] [kmax] [extent]
+usage: poly_bench.py [pairs] [reps] [kmin] [kmax] [extent] [sorted]   ("sorted": pairs ordered by (ka, kb), so that a
+wave's pairs have equal vertex counts and the rows above them are skipped: traffic = the exact bytes)
 C2D_LIBRARY=<other libc2d.so> selects another build of the same C-ABI for A/B runs."""
 import os
 import sys
@@ -28,6 +29,9 @@ def main():
     dev = torch.device("cuda", 0)
     eng = pkg.Engine(0)
     vx, vy, kk = torch_random_convex_polygons(torch, dev, n, seed=0xC0FFEE, kmin=kmin, kmax=kmax, extent=extent)
+    if len(sys.argv) > 6 and sys.argv[6] == "sorted":
+        order = torch.argsort(kk[0].to(torch.int64) * 32 + kk[1].to(torch.int64))
+        vx, vy, kk = vx[:, :, order].contiguous(), vy[:, :, order].contiguous(), kk[:, order].contiguous()
     out = torch.zeros(n, dtype=torch.uint8, device=dev)
     cnt = torch.zeros(1, dtype=torch.int64, device=dev)
     stream = torch.cuda.Stream(device=dev)
