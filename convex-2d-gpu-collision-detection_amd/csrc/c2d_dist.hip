@@ -46,10 +46,9 @@ struct Rccl {
     std::string error;
 };
 
-Rccl& rccl()
+Rccl load_rccl()
 {
-    static Rccl r;
-    if (r.handle || !r.error.empty()) return r;
+    Rccl r;
     for (const char* name : {"librccl.so.1", "librccl.so"}) {
         r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         if (r.handle) break;
@@ -75,6 +74,13 @@ Rccl& rccl()
         dlclose(r.handle);
         r.handle = nullptr;
     }
+    return r;
+}
+
+// loaded once, at the first c2d_dist_* call that needs it (initialisation of a local static is thread-safe)
+Rccl& rccl()
+{
+    static Rccl r = load_rccl();
     return r;
 }
 
@@ -306,6 +312,7 @@ int c2d_dist_destroy(c2d_dist* d)
         // once they have entered destroy too, which a final barrier establishes
         if (d->world > 1) {
             unsigned long long z = 0;
+            if (d->timeout_s > 10.0) d->timeout_s = 10.0;  // a peer that died must not hold this rank's exit for minutes
             (void)file_all_reduce(d, &z, 1);
         }
         for (uint64_t s = d->seq >= 3 ? d->seq - 3 : 0; s < d->seq; s++)

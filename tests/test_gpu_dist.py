@@ -191,3 +191,31 @@ def test_bench_starts_its_own_ranks(tmp_path):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--backend", "gloo", "--pairs", "-5"] + small[6:],
                          capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode != 0 and not out.stdout.strip()
+
+
+def test_c2d_dist_error_paths(eng, pkg, tmp_path):
+    """A rank that never finds its peers gets C2D_ERR_DIST within the timeout instead of hanging; bad arguments are refused."""
+    import time
+
+    t0 = time.time()
+    with pytest.raises(pkg.C2DError) as ei:
+        eng.dist_init_file(1, 2, str(tmp_path / "never_written"), 1.0)     # rank 0 never writes the id
+    assert ei.value.status == -6 and time.time() - t0 < 10 and "id file" in str(ei.value)
+    with pytest.raises(pkg.C2DError):
+        eng.dist_init_file(0, 0, str(tmp_path / "x"), 1.0)
+    with pytest.raises(ValueError):
+        eng.dist_init(0, 1, b"short")
+    # the file transport named in an id made under C2D_DIST_TRANSPORT=file works with one rank too and reports itself
+    os.environ["C2D_DIST_TRANSPORT"] = "file"
+    try:
+        d = eng.dist_init(0, 1, eng.dist_unique_id())
+    finally:
+        del os.environ["C2D_DIST_TRANSPORT"]
+    assert d.transport == "file (rehearsal)" and d.world_size == 1
+    buf = eng.to_device(np.array([7, 9], np.uint64))
+    d.all_reduce_sum_u64(buf, 2)
+    d.broadcast_u64(buf, 2)
+    d.barrier()
+    assert buf.get().tolist() == [7, 9]
+    d.close()
+    buf.free()
