@@ -353,6 +353,10 @@ def main() -> None:
                     "bytes_per_pair": 64.125,
                     "roofline": {"bound": "hbm", "kernel": "sat_rect_verts_mask4_kernel", "achieved": round(mgbs, 1), "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": round(mgbs / HBM_PEAK_GBS, 4), "traffic": None}}
+        c = counts.get("sat_rect_verts_mask.config2")
+        if c and n == c.get("pairs"):
+            mask_leg["roofline"]["traffic"] = c.get("hbm_bytes_per_launch")
+            mask_leg["roofline"]["traffic_source"] = "recorded, not measured in this run: %s" % c.get("source")
         del mwords
 
     # ---- secondary input format: poses (41 B/pair), reported separately ----------

@@ -79,20 +79,22 @@ __global__ __launch_bounds__(64) void sat_rect_verts_mask4_kernel(Planes16 P, si
                                                                   unsigned long long* __restrict__ words)
 {
     const uint32_t lane = threadIdx.x;
-    const size_t g = (size_t)blockIdx.x * 64 + lane;  // n_groups is a multiple of 64: every wave is full
-    f32x4 v[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) v[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P.p[k]) + g);
+    const size_t g = (size_t)blockIdx.x * 64 + lane;  // n_groups is a multiple of 16: a 16-lane row (one word) is all in or all out
     uint32_t nib = 0;
+    if (g < n_groups) {
+        f32x4 v[16];
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-        float r1[8], r2[8];
+        for (int k = 0; k < 16; k++) v[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P.p[k]) + g);
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            r1[k] = v[k][e];
-            r2[k] = v[8 + k][e];
+        for (int e = 0; e < 4; e++) {
+            float r1[8], r2[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                r1[k] = v[k][e];
+                r2[k] = v[8 + k][e];
+            }
+            nib |= (rect_collide(r1, r2) ? 1u : 0u) << e;
         }
-        nib |= (rect_collide(r1, r2) ? 1u : 0u) << e;
     }
     const uint32_t sh = 4u * (lane & 15u);
     uint32_t lo = sh < 32u ? nib << sh : 0u, hi = sh >= 32u ? nib << (sh - 32u) : 0u;
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(64) void sat_rect_verts_mask4_kernel(Planes16 P, si
         lo |= (uint32_t)__shfl_xor((int)lo, off, 64);
         hi |= (uint32_t)__shfl_xor((int)hi, off, 64);
     }
-    if ((lane & 15u) == 0) __builtin_nontemporal_store(((unsigned long long)hi << 32) | lo, mask + ((size_t)blockIdx.x * 4 + (lane >> 4)));
+    if ((lane & 15u) == 0 && g < n_groups) __builtin_nontemporal_store(((unsigned long long)hi << 32) | lo, mask + ((size_t)blockIdx.x * 4 + (lane >> 4)));
     if (d_count) wave_count_arrive((uint32_t)__popc(nib), d_count, words);
 }
 
@@ -339,15 +341,16 @@ int c2d_sat_rect_pairs_verts_mask(c2d_ctx* ctx, const float* const d_planes[16],
     hipStream_t s = (hipStream_t)stream;
     if (int rc = workspace_acquire(ctx, s, d_count != nullptr)) return rc;
     size_t done = 0;
-    while (wide && n - done >= 256) {  // full waves of 256 pairs; more than kMaxBlocks of them go in several launches
-        size_t waves = (n - done) / 256;
-        if (waves > (size_t)kMaxBlocks) waves = (size_t)kMaxBlocks;
+    while (wide && n - done >= 64) {  // whole 64-bit words; more than kMaxBlocks waves go in several launches
+        size_t words_left = (n - done) / 64;
+        if (words_left > (size_t)kMaxBlocks * 4) words_left = (size_t)kMaxBlocks * 4;
         Planes16 Q;
         for (int k = 0; k < 16; k++) Q.p[k] = P.p[k] + done;
-        hipLaunchKernelGGL(sat_rect_verts_mask4_kernel, dim3((unsigned)waves), dim3(64), 0, s, Q, waves * 64, d_mask + done / 64, d_count,
+        const size_t groups = words_left * 16;
+        hipLaunchKernelGGL(sat_rect_verts_mask4_kernel, dim3((unsigned)((groups + 63) / 64)), dim3(64), 0, s, Q, groups, d_mask + done / 64, d_count,
                            ctx->d_count_words);
         C2D_LAUNCH_CHECK(ctx);
-        done += waves * 256;
+        done += words_left * 64;
     }
     if (done < n) {
         const int grid = grid_for(n - done, kBlock, kMaxBlocks);
