@@ -259,6 +259,33 @@ __global__ __launch_bounds__(kBlock) void rects_from_poses_kernel(const float* _
     }
 }
 
+// wide form: a lane builds 4 consecutive rectangles, 5 x 16-byte loads and 8 x 16-byte stores (520 B per lane);
+// single-wave blocks without a grid-stride loop, as for the SAT kernels
+__global__ __launch_bounds__(kWideBlock) void rects_from_poses4_kernel(const float* __restrict__ cx, const float* __restrict__ cy,
+                                                                       const float* __restrict__ w, const float* __restrict__ h,
+                                                                       const float* __restrict__ th, size_t n_groups, Planes8 O)
+{
+    const size_t stride = (size_t)gridDim.x * kWideBlock;
+    for (size_t g = (size_t)blockIdx.x * kWideBlock + threadIdx.x; g < n_groups; g += stride) {
+        const f32x4 vcx = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(cx) + g);
+        const f32x4 vcy = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(cy) + g);
+        const f32x4 vw = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(w) + g);
+        const f32x4 vh = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(h) + g);
+        const f32x4 vt = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(th) + g);
+        f32x4 o[8];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            float r[8], s, c;
+            sincos_(vt[e], s, c);
+            rect_from_half_extents(vw[e] / 2, vh[e] / 2, c, s, vcx[e], vcy[e], r);
+#pragma unroll
+            for (int k = 0; k < 8; k++) o[k][e] = r[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) __builtin_nontemporal_store(o[k], reinterpret_cast<f32x4*>(O.p[k]) + g);
+    }
+}
+
 static inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
 }  // namespace c2d
@@ -279,10 +306,22 @@ int c2d_rects_from_poses(c2d_ctx* ctx, const float* d_cx, const float* d_cy, con
         O.p[k] = d_out_planes[k];
     }
     DeviceGuard g(ctx->device);
-    const int grid = grid_for(n, kBlock, ctx->prop.multiProcessorCount * 8);
-    hipLaunchKernelGGL(rects_from_poses_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, d_cx, d_cy, d_w, d_h,
-                       d_theta, n, O);
-    C2D_LAUNCH_CHECK(ctx);
+    bool wide = aligned_to(d_cx, 16) && aligned_to(d_cy, 16) && aligned_to(d_w, 16) && aligned_to(d_h, 16) && aligned_to(d_theta, 16);
+    for (int k = 0; k < 8; k++) wide = wide && aligned_to(O.p[k], 16);
+    const size_t n4 = wide ? n / 4 : 0;
+    if (n4) {
+        hipLaunchKernelGGL(rects_from_poses4_kernel, dim3(grid_for(n4, kWideBlock, kMaxBlocks)), dim3(kWideBlock), 0, (hipStream_t)stream, d_cx, d_cy,
+                           d_w, d_h, d_theta, n4, O);
+        C2D_LAUNCH_CHECK(ctx);
+    }
+    const size_t rest = n - 4 * n4;
+    if (rest) {
+        Planes8 T;
+        for (int k = 0; k < 8; k++) T.p[k] = O.p[k] + 4 * n4;
+        hipLaunchKernelGGL(rects_from_poses_kernel, dim3(grid_for(rest, kBlock, ctx->prop.multiProcessorCount * 8)), dim3(kBlock), 0,
+                           (hipStream_t)stream, d_cx + 4 * n4, d_cy + 4 * n4, d_w + 4 * n4, d_h + 4 * n4, d_theta + 4 * n4, rest, T);
+        C2D_LAUNCH_CHECK(ctx);
+    }
     return C2D_OK;
 }
 

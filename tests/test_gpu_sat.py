@@ -187,6 +187,24 @@ def test_full_size_properties_1e7(eng, wl):
         a.free()
 
 
+@pytest.mark.parametrize("n,offset", [(1, 0), (3, 0), (4, 0), (5, 0), (1023, 0), (100_001, 0), (4096, 1), (777, 3)])
+def test_rects_from_poses_ragged_and_unaligned(eng, oracle, wl, n, offset):
+    """create_rect + rot_trans_rectangle over SoA: the 4-rectangles-per-lane path, its tail, and planes that are not
+    16-byte aligned (one rectangle per lane) all give the oracle's vertices bit for bit."""
+    poses = wl.random_obb_pose_planes(n, seed=7 + n)[:5]
+    host = np.zeros((5, n + 8), np.float32)
+    host[:, offset:offset + n] = poses
+    d_in = eng.to_device(host)
+    d_out = eng.zeros((8, n + 8), np.float32)
+    eng.rects_from_poses(*[d_in.row(k) + 4 * offset for k in range(5)], n, [d_out.row(k) + 4 * offset for k in range(8)])
+    got = d_out.get()
+    ref = oracle.rects_from_poses(*poses)
+    assert np.array_equal(got[:, offset:offset + n].view(np.uint32), ref.view(np.uint32))
+    assert not got[:, :offset].any() and not got[:, offset + n:].any()        # nothing written outside
+    d_in.free()
+    d_out.free()
+
+
 @pytest.mark.parametrize("n,offset", [(1, 0), (63, 0), (64, 0), (65, 0), (255, 0), (256, 0), (257, 0), (1000, 0), (100_003, 0),
                                       (1_000_003, 0), (5000, 1), (70_001, 3)])
 def test_bit_mask_output(eng, oracle, wl, n, offset):
