@@ -198,22 +198,29 @@ def main() -> None:
     if use_dist:
         reduce_impl = "torch.distributed all_reduce (%s)" % args.backend
         if args.reduce == "c2d":
-            ok = 1
-            try:
-                if args.backend == "nccl":
-                    id_t = torch.zeros(pkg.binding.DIST_ID_BYTES, dtype=torch.uint8, device=dev)
-                    if rank == 0:
-                        id_t.copy_(torch.frombuffer(bytearray(eng.dist_unique_id()), dtype=torch.uint8))
-                    dist.broadcast(id_t, 0)
-                    uid = bytes(id_t.cpu().numpy().tobytes())
-                else:
-                    box = [eng.dist_unique_id() if rank == 0 else None]
-                    dist.broadcast_object_list(box, 0)
-                    uid = box[0]
-                cdist = eng.dist_init(rank, world, uid)
-            except Exception as e:  # noqa: BLE001
-                print(f"[bench] rank {rank}: c2d_dist unavailable ({e}); falling back to torch.distributed", file=sys.stderr)
-                ok = 0
+            # rank 0 creates the id; it is broadcast whether or not that worked (an all-zero id = "could not"), so that a
+            # failure on one rank never leaves the others waiting in a collective
+            raw = bytes(pkg.binding.DIST_ID_BYTES)
+            if rank == 0:
+                try:
+                    raw = eng.dist_unique_id()
+                except Exception as e:  # noqa: BLE001
+                    print(f"[bench] rank 0: c2d_dist_unique_id failed ({e})", file=sys.stderr)
+            if args.backend == "nccl":
+                id_t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+                dist.broadcast(id_t, 0)
+                uid = id_t.cpu().numpy().tobytes()
+            else:
+                box = [raw]
+                dist.broadcast_object_list(box, 0)
+                uid = box[0]
+            ok = 0
+            if any(uid):
+                try:
+                    cdist = eng.dist_init(rank, world, uid)
+                    ok = 1
+                except Exception as e:  # noqa: BLE001
+                    print(f"[bench] rank {rank}: c2d_dist_init failed ({e}); falling back to torch.distributed", file=sys.stderr)
             flag = torch.tensor([ok], dtype=torch.int32, device=dev if args.backend == "nccl" else None)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 1:
