@@ -93,6 +93,7 @@ _SIGNATURES = {
     "c2d_sat_rect_pairs_aos": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "c2d_sat_rect_pairs_pose": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "c2d_sat_poly_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "c2d_sat_poly_pairs_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "c2d_philox_normals": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "c2d_math_eval": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "c2d_mc_pair": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.POINTER(_Position), C.POINTER(_Pose), C.POINTER(_StdDev),
@@ -352,6 +353,10 @@ class Engine:
         arr = (C.c_void_p * 10)(*[_ptr_of(p) for p in planes])
         self._check(self.lib.c2d_sat_rect_pairs_pose(self.h, arr, n, _ptr_of(out), _ptr_of(count), C.c_void_p(stream)),
                     "c2d_sat_rect_pairs_pose")
+
+    def sat_poly_pairs_rows(self, vx, vy, k, n: int, rows: int, out, count=None, stream: int = 0):
+        self._check(self.lib.c2d_sat_poly_pairs_rows(self.h, _ptr_of(vx), _ptr_of(vy), _ptr_of(k), n, rows, _ptr_of(out), _ptr_of(count),
+                                                     C.c_void_p(stream)), "c2d_sat_poly_pairs_rows")
 
     def sat_poly_pairs(self, vx, vy, k, n: int, out, count=None, stream: int = 0):
         self._check(self.lib.c2d_sat_poly_pairs(self.h, _ptr_of(vx), _ptr_of(vy), _ptr_of(k), n, _ptr_of(out), _ptr_of(count),

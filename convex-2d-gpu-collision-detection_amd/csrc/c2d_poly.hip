@@ -31,8 +31,7 @@
 
 namespace c2d {
 
-constexpr int KM = C2D_POLY_KMAX;  // 16
-constexpr int kSlots = 8;          // undecided pairs parked in LDS per group (256 B each)
+constexpr int kSlots = 8;          // undecided pairs parked in LDS per group (16 KM bytes each)
 
 C2D_DEV void minmax_update(float nx, float ny, float x, float y, float& mn, float& mx)
 {
@@ -51,14 +50,21 @@ C2D_DEV uint32_t wave_max_u32(uint32_t v)
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 
-// One wave = one tile of 64 pairs.
-__global__ __launch_bounds__(64, 5) void sat_poly_kernel(const float* __restrict__ vx, const float* __restrict__ vy,
-                                                      const uint8_t* __restrict__ kcnt, size_t n,
-                                                      uint8_t* __restrict__ out,
-                                                      unsigned long long* __restrict__ d_count,
-                                                      unsigned long long* __restrict__ words,
-                                                      uint32_t* __restrict__ async_err)
+// One wave = one tile of 64 pairs.  KM (4, 8 or 16) is the number of vertex slots a lane holds per polygon: the
+// smallest that covers the layout's `rows` (vertex rows per polygon in memory, f32[2][rows][n]).  Small polygons
+// then cost a quarter or half of the registers (8 waves per SIMD instead of 5), a shorter instruction stream, and
+// in phase 2 four or eight pairs share a wave instead of two.
+template <int KM, int MIN_WAVES, bool FULL>
+__global__ __launch_bounds__(64, MIN_WAVES) void sat_poly_kernel(const float* __restrict__ vx, const float* __restrict__ vy,
+                                                                 const uint8_t* __restrict__ kcnt, size_t n, int rows_arg,
+                                                                 uint8_t* __restrict__ out,
+                                                                 unsigned long long* __restrict__ d_count,
+                                                                 unsigned long long* __restrict__ words,
+                                                                 uint32_t* __restrict__ async_err)
 {
+    const int rows = FULL ? KM : rows_arg;  // FULL: the layout has exactly KM rows (a compile-time constant)
+    constexpr int LP = 2 * KM;      // lanes per pair in phase 2 = axis slots of a pair
+    constexpr int PP = 64 / LP;     // pairs evaluated side by side in phase 2
     // phase-2 slots: A's 16 vertices then B's 16 vertices, (x, y) interleaved
     __shared__ __attribute__((aligned(16))) float2 s_slot[kSlots][2 * KM];
     const uint32_t lane = threadIdx.x;
@@ -71,9 +77,9 @@ __global__ __launch_bounds__(64, 5) void sat_poly_kernel(const float* __restrict
         const uint32_t cl = in ? lane : here - 1;  // lanes past the end re-read the last pair (never stored)
         // ---- vertex counts; out-of-range counts are clamped (memory safety) and reported -------
         int ka = kcnt[p0 + cl], kb = kcnt[n + p0 + cl];
-        const bool bad = ka < 1 || ka > KM || kb < 1 || kb > KM;
-        ka = ka < 1 ? 1 : (ka > KM ? KM : ka);
-        kb = kb < 1 ? 1 : (kb > KM ? KM : kb);
+        const bool bad = ka < 1 || ka > rows || kb < 1 || kb > rows;
+        ka = ka < 1 ? 1 : (ka > rows ? rows : ka);
+        kb = kb < 1 ? 1 : (kb > rows ? rows : kb);
         if (__ballot(bad) != 0 && lane == 0) __hip_atomic_fetch_or(async_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const int kmaxA = (int)wave_max_u32((uint32_t)ka), kmaxB = (int)wave_max_u32((uint32_t)kb);
         // ---- rows: scalar base + 32-bit lane offset, rows >= the wave's maximum are skipped ------
@@ -99,6 +105,10 @@ __global__ __launch_bounds__(64, 5) void sat_poly_kernel(const float* __restrict
             }
             rx += n;
             ry += n;
+        }
+        if constexpr (!FULL) {  // polygon B starts `rows` rows in (with rows == KM the pointers are already there)
+            rx = vx + (size_t)rows * n + p0;
+            ry = vy + (size_t)rows * n + p0;
         }
 #pragma unroll
         for (int r = 0; r < KM; r++) {
@@ -165,15 +175,19 @@ __global__ __launch_bounds__(64, 5) void sat_poly_kernel(const float* __restrict
         bool sep = (mxA < mnB) || (mxB < mnA);
         sep = sep || bad;  // out-of-range vertex count: reported, result 0
         // ---- phase 2: full evaluation of the pairs that are still undecided -------------------------------
-        // Up to kSlots undecided lanes park their vertices at once (the 16 ds_write_b128 are issued once per
-        // group, not once per pair); then each HALF-wave evaluates one parked pair: lane a of the half owns
-        // axis slot a (A's edges 0..15, B's edges 16..31) and projects all vertices of both polygons, two per
-        // broadcast ds_read_b128, so "some axis separates" is one ballot half and no lane exchange is needed.
+        // Up to kSlots undecided lanes park their vertices at once (the ds_write_b128 are issued once per group, not
+        // once per pair); then PP pairs are evaluated side by side, LP = 2 KM lanes each: lane a of a pair's lanes owns
+        // axis slot a (A's edges 0..KM-1, B's edges KM..2KM-1) and projects all vertices of both polygons, two per
+        // broadcast ds_read_b128, so "some axis separates" is one slice of a ballot and no lane exchange is needed.
         unsigned long long todo = __ballot(in && !sep);
-        const int a = (int)(lane & 31u);
-        const int half = (int)(lane >> 5);
-        const int i0 = a, i1 = (a & KM) | ((a + 1) & (KM - 1));
         while (todo) {
+            // lane roles of phase 2, derived here (from an opaque copy of the lane id, so that they are not hoisted
+            // into phase 1 where every register holds a vertex)
+            uint32_t lane2 = lane;
+            asm volatile("" : "+v"(lane2));
+            const int a = (int)(lane2 % LP);
+            const int sub = (int)(lane2 / LP);
+            const int i0 = a, i1 = (a & KM) | ((a + 1) & (KM - 1));
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u));
             const bool park = ((todo >> lane) & 1ull) && rank < (uint32_t)kSlots;
             __syncthreads();  // single-wave block: a wave-level fence (no s_barrier is emitted); earlier reads are done
@@ -188,40 +202,49 @@ __global__ __launch_bounds__(64, 5) void sat_poly_kernel(const float* __restrict
             __syncthreads();
             const int left = __popcll(todo);
             const int g = left < kSlots ? left : kSlots;
-            for (int i = 0; i < g; i += 2) {
-                const int j0 = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                const bool two = i + 1 < g;
-                const int j1 = two ? __ffsll((long long)todo) - 1 : j0;
-                if (two) todo &= todo - 1;
-                const int kA0 = __builtin_amdgcn_readlane(ka, j0), kA1 = __builtin_amdgcn_readlane(ka, j1);
-                const int kB0 = __builtin_amdgcn_readlane(kb, j0), kB1 = __builtin_amdgcn_readlane(kb, j1);
-                const int kA = kA0 > kA1 ? kA0 : kA1, kB = kB0 > kB1 ? kB0 : kB1;  // wave-uniform loop bounds
-                const float2* S = &s_slot[i + (two ? half : 0)][0];  // a lone last pair is evaluated by both halves
+            for (int i = 0; i < g; i += PP) {
+                const int cnt = (g - i) < PP ? (g - i) : PP;  // pairs of this trip (wave-uniform)
+                int j[PP];
+                int kA = 0, kB = 0;  // wave-uniform loop bounds: the largest counts among the trip's pairs
+#pragma unroll
+                for (int q = 0; q < PP; q++) {
+                    j[q] = -1;
+                    if (q < cnt) {
+                        j[q] = __ffsll((long long)todo) - 1;
+                        todo &= todo - 1;
+                        const int kaq = __builtin_amdgcn_readlane(ka, j[q]), kbq = __builtin_amdgcn_readlane(kb, j[q]);
+                        kA = kaq > kA ? kaq : kA;
+                        kB = kbq > kB ? kbq : kB;
+                    }
+                }
+                const float2* S = &s_slot[i + (sub < cnt ? sub : 0)][0];  // lanes without a pair of their own repeat the first
                 const float4* S4 = reinterpret_cast<const float4*>(S);
                 const float2 e0 = S[i0], e1 = S[i1];
                 const float nx = -(e1.y - e0.y), ny = e1.x - e0.x;
                 float mn1 = __builtin_inff(), mx1 = -__builtin_inff(), mn2 = __builtin_inff(), mx2 = -__builtin_inff();
-                // slots past a polygon's count repeat its vertex 0, so running to the larger count of the two
+                // slots past a polygon's count repeat its vertex 0, so running to the largest count of the trip's
                 // pairs (rounded up to a vertex pair) needs no masking; one read ahead hides the LDS latency
-                float4 q = S4[0];
+                float4 q4 = S4[0];
                 for (int r2 = 0; 2 * r2 < kA; r2++) {
-                    const float4 qn = S4[r2 + 1];  // r2 + 1 <= 8: at worst B's first pair, always inside the slot
-                    minmax_update(nx, ny, q.x, q.y, mn1, mx1);
-                    minmax_update(nx, ny, q.z, q.w, mn1, mx1);
-                    q = qn;
+                    const float4 qn = S4[r2 + 1];  // r2 + 1 <= KM / 2: at worst B's first pair, always inside the slot
+                    minmax_update(nx, ny, q4.x, q4.y, mn1, mx1);
+                    minmax_update(nx, ny, q4.z, q4.w, mn1, mx1);
+                    q4 = qn;
                 }
-                q = S4[KM / 2];
+                q4 = S4[KM / 2];
                 for (int r2 = 0; 2 * r2 < kB; r2++) {
                     const float4 qn = S4[KM / 2 + ((r2 + 1) & (KM / 2 - 1))];
-                    minmax_update(nx, ny, q.x, q.y, mn2, mx2);
-                    minmax_update(nx, ny, q.z, q.w, mn2, mx2);
-                    q = qn;
+                    minmax_update(nx, ny, q4.x, q4.y, mn2, mx2);
+                    minmax_update(nx, ny, q4.z, q4.w, mn2, mx2);
+                    q4 = qn;
                 }
                 const unsigned long long bal = __ballot((mx1 < mn2) || (mx2 < mn1));
-                const bool any0 = (uint32_t)bal != 0u, any1 = (uint32_t)(bal >> 32) != 0u;
-                sep = ((int)lane == j0) ? any0 : sep;
-                sep = (two && (int)lane == j1) ? any1 : sep;
+                constexpr unsigned long long kPairMask = LP == 64 ? ~0ull : ((1ull << LP) - 1ull);
+#pragma unroll
+                for (int q = 0; q < PP; q++) {
+                    const bool any = ((bal >> (q * LP)) & kPairMask) != 0ull;
+                    sep = ((int)lane == j[q]) ? any : sep;  // j[q] == -1 matches no lane
+                }
             }
         }
         const bool collide = in && !sep;
@@ -231,24 +254,46 @@ __global__ __launch_bounds__(64, 5) void sat_poly_kernel(const float* __restrict
     if (d_count) wave_count_arrive_total(n_collide, d_count, words);
 }
 
+template <int KM, int MIN_WAVES, bool FULL>
+static void launch_poly(hipStream_t s, const float* d_vx, const float* d_vy, const uint8_t* d_k, size_t n, int rows, uint8_t* d_out,
+                        unsigned long long* d_count, unsigned long long* words, uint32_t* async_err)
+{
+    const size_t n_tiles = (n + 63) / 64;
+    const int grid = (int)(n_tiles < (size_t)kMaxGrid ? n_tiles : (size_t)kMaxGrid);
+    hipLaunchKernelGGL((sat_poly_kernel<KM, MIN_WAVES, FULL>), dim3(grid), dim3(64), 0, s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words, async_err);
+}
+
 }  // namespace c2d
 
 using namespace c2d;
 
-extern "C" int c2d_sat_poly_pairs(c2d_ctx* ctx, const float* d_vx, const float* d_vy, const uint8_t* d_k, size_t n,
-                                  uint8_t* d_out, unsigned long long* d_count, c2d_stream stream)
+extern "C" {
+
+int c2d_sat_poly_pairs_rows(c2d_ctx* ctx, const float* d_vx, const float* d_vy, const uint8_t* d_k, size_t n, int rows,
+                            uint8_t* d_out, unsigned long long* d_count, c2d_stream stream)
 {
     if (!ctx) return C2D_ERR_INVALID_ARG;
+    if (rows < 1 || rows > C2D_POLY_KMAX) return fail_arg(ctx, "c2d_sat_poly_pairs_rows: rows must be 1..C2D_POLY_KMAX");
     if (n == 0) return C2D_OK;
     if (!d_vx || !d_vy || !d_k || !d_out) return fail_arg(ctx, "c2d_sat_poly_pairs: NULL argument");
     DeviceGuard g(ctx->device);
     hipStream_t s = (hipStream_t)stream;
     if (int rc = workspace_acquire(ctx, s, d_count != nullptr)) return rc;
-    const size_t n_tiles = (n + 63) / 64;
-    const int grid = (int)(n_tiles < (size_t)kMaxGrid ? n_tiles : (size_t)kMaxGrid);
-    hipLaunchKernelGGL(sat_poly_kernel, dim3(grid), dim3(64), 0, s, d_vx, d_vy, d_k, n, d_out, d_count, ctx->d_count_words,
-                       ctx->d_async_err);
+    uint32_t* err = ctx->d_async_err;
+    unsigned long long* words = ctx->d_count_words;
+    if (rows == 16) launch_poly<16, 5, true>(s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words, err);
+    else if (rows > 8) launch_poly<16, 5, false>(s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words, err);
+    else if (rows > 4) launch_poly<8, 7, false>(s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words, err);
+    else launch_poly<4, 8, false>(s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words, err);
     C2D_LAUNCH_CHECK(ctx);
     workspace_release(ctx, s, d_count != nullptr);
     return C2D_OK;
 }
+
+int c2d_sat_poly_pairs(c2d_ctx* ctx, const float* d_vx, const float* d_vy, const uint8_t* d_k, size_t n, uint8_t* d_out,
+                       unsigned long long* d_count, c2d_stream stream)
+{
+    return c2d_sat_poly_pairs_rows(ctx, d_vx, d_vy, d_k, n, C2D_POLY_KMAX, d_out, d_count, stream);
+}
+
+}  // extern "C"

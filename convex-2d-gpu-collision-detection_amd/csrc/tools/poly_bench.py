@@ -2,7 +2,9 @@
 """Developer tool: time c2d_sat_poly_pairs on the BASELINE config-5 workload (HIP events on the
 kernel's stream) and check a sample against the CPU oracle.  TEST INFRASTRUCTURE (uses oracle/).
 
-usage: poly_bench.py [pairs] [reps] [kmin] [kmax] [extent] [sorted]   ("sorted": pairs ordered by (ka, kb), so that a
+usage: poly_bench.py [pairs] [reps] [kmin] [kmax] [extent] [sorted|rowsN]   ("rowsN": layout with N vertex rows per polygon,
+c2d_sat_poly_pairs_rows)
+       poly_bench.py [pairs] [reps] [kmin] [kmax] [extent] [sorted]   ("sorted": pairs ordered by (ka, kb), so that a
 wave's pairs have equal vertex counts and the rows above them are skipped: traffic = the exact bytes)
 C2D_LIBRARY=<other libc2d.so> selects another build of the same C-ABI for A/B runs."""
 import os
@@ -29,6 +31,10 @@ def main():
     dev = torch.device("cuda", 0)
     eng = pkg.Engine(0)
     vx, vy, kk = torch_random_convex_polygons(torch, dev, n, seed=0xC0FFEE, kmin=kmin, kmax=kmax, extent=extent)
+    rows = 16
+    if len(sys.argv) > 6 and sys.argv[6].startswith("rows"):
+        rows = int(sys.argv[6][4:])
+        vx, vy = vx[:, :rows, :].contiguous(), vy[:, :rows, :].contiguous()
     if len(sys.argv) > 6 and sys.argv[6] == "sorted":
         order = torch.argsort(kk[0].to(torch.int64) * 32 + kk[1].to(torch.int64))
         vx, vy, kk = vx[:, :, order].contiguous(), vy[:, :, order].contiguous(), kk[:, order].contiguous()
@@ -39,7 +45,7 @@ def main():
     torch.cuda.synchronize()  # the inputs were generated on torch's current stream
 
     def step():
-        eng.sat_poly_pairs(vx.data_ptr(), vy.data_ptr(), kk.data_ptr(), n, out.data_ptr(), cnt.data_ptr(), stream=sh)
+        eng.sat_poly_pairs_rows(vx.data_ptr(), vy.data_ptr(), kk.data_ptr(), n, rows, out.data_ptr(), cnt.data_ptr(), stream=sh)
 
     for _ in range(5):
         step()
@@ -57,8 +63,8 @@ def main():
     eng.check_async()
     ms = float(np.median(times))
     exact = int(kk.to(torch.int64).sum().item()) * 8 + 3 * n
-    print(f"pairs {n} K~U{{{kmin}..{kmax}}} extent {extent}: median {ms:.4f} ms  min {min(times):.4f}  "
-          f"{n / ms / 1e6:.3f} Gpairs/s  padded {259 * n / ms / 1e6:.0f} GB/s ({259 * n / ms / 1e6 / 8000:.3f} of 8 TB/s)  "
+    print(f"pairs {n} K~U{{{kmin}..{kmax}}} rows {rows} extent {extent}: median {ms:.4f} ms  min {min(times):.4f}  "
+          f"{n / ms / 1e6:.3f} Gpairs/s  layout {(16 * rows + 3) * n / ms / 1e6:.0f} GB/s ({(16 * rows + 3) * n / ms / 1e6 / 8000:.3f} of 8 TB/s)  "
           f"exact {exact / ms / 1e6:.0f} GB/s  collide rate {cnt.item() / reps / n:.4f}")
     m = min(n, 300_000)
     sel = slice(n - m, n)

@@ -36,17 +36,18 @@ def random_obb_pose_planes(n: int, seed: int = 0x5A7, extent: float = 8.0) -> np
     return out
 
 
-def random_convex_polygons(n: int, seed: int = 0xC0FFEE, kmin: int = 3, kmax: int = KMAX, extent: float = 8.0):
-    """BASELINE config 5 input: vx, vy float32 [2][KMAX][n], k uint8 [2][n].
-    Each polygon has K ~ U{kmin..kmax} vertices at sorted random angles on an
+def random_convex_polygons(n: int, seed: int = 0xC0FFEE, kmin: int = 3, kmax: int = KMAX, extent: float = 8.0, rows: int = KMAX):
+    """BASELINE config 5 input: vx, vy float32 [2][rows][n] (rows = KMAX unless a tighter layout is asked for),
+    k uint8 [2][n].  Each polygon has K ~ U{kmin..kmax} vertices at sorted random angles on an
     ellipse (hence convex, counter-clockwise), randomly rotated and placed."""
+    assert kmax <= rows <= KMAX
     rng = np.random.Generator(np.random.Philox(seed))
-    vx = np.zeros((2, KMAX, n), np.float32)
-    vy = np.zeros((2, KMAX, n), np.float32)
+    vx = np.zeros((2, rows, n), np.float32)
+    vy = np.zeros((2, rows, n), np.float32)
     k = rng.integers(kmin, kmax + 1, size=(2, n)).astype(np.uint8)
     for p in range(2):
-        mask = np.arange(KMAX)[:, None] >= k[p][None, :]
-        ang = rng.uniform(0.0, 2.0 * np.pi, size=(KMAX, n))
+        mask = np.arange(rows)[:, None] >= k[p][None, :]
+        ang = rng.uniform(0.0, 2.0 * np.pi, size=(rows, n))
         ang[mask] = np.inf                      # unused slots sort to the end
         ang = np.sort(ang, axis=0)              # the K used angles ascend: counter-clockwise
         ang[mask] = 0.0

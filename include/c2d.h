@@ -174,6 +174,16 @@ int c2d_sat_rect_pairs_pose(c2d_ctx* ctx, const float* const d_pose_planes[10], 
 int c2d_sat_poly_pairs(c2d_ctx* ctx, const float* d_vx, const float* d_vy, const uint8_t* d_k,
                        size_t n, uint8_t* d_out, unsigned long long* d_count, c2d_stream stream);
 
+/* c2d_sat_poly_pairs_rows: the same test on a layout with `rows` vertex rows per polygon instead of
+ * C2D_POLY_KMAX — d_vx, d_vy : f32[2][rows][n], vertex counts 1..rows, 1 <= rows <= C2D_POLY_KMAX.
+ * Batches of small polygons (triangles and quadrilaterals: rows = 4; up to octagons: rows = 8) take
+ * a quarter or half of the memory and run a kernel instance sized for them (fewer registers, more
+ * waves per SIMD, four or eight pairs per wave in the full evaluation).  rows = C2D_POLY_KMAX is
+ * c2d_sat_poly_pairs. */
+int c2d_sat_poly_pairs_rows(c2d_ctx* ctx, const float* d_vx, const float* d_vy, const uint8_t* d_k,
+                            size_t n, int rows, uint8_t* d_out, unsigned long long* d_count,
+                            c2d_stream stream);
+
 /* ---- random stream -----------------------------------------------------------
  * Replaces setup_kernel + curand_normal (utils.cu:111-117, :146-150).  The
  * generator is counter based: Philox4x32-10 with key = seed, counter =

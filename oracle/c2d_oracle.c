@@ -390,31 +390,38 @@ unsigned long long c2d_oracle_sat_rect_pairs_pose(const float* const pp[10], siz
     return count;
 }
 
-/* vx, vy: f32[2][KMAX][n]; k: u8[2][n].  Returns the colliding count, or
- * (unsigned long long)-1 on a vertex count outside 1..KMAX. */
-unsigned long long c2d_oracle_sat_poly_pairs(const float* vx, const float* vy, const uint8_t* k,
-                                             size_t n, uint8_t* out)
+/* vx, vy: f32[2][rows][n] (rows vertex rows per polygon, 1..KMAX); k: u8[2][n].  Returns the colliding count, or
+ * (unsigned long long)-1 on a vertex count outside 1..rows (those pairs read 0). */
+unsigned long long c2d_oracle_sat_poly_pairs_rows(const float* vx, const float* vy, const uint8_t* k,
+                                                  size_t n, int rows, uint8_t* out)
 {
     unsigned long long count = 0;
     int bad = 0;
+    if (rows < 1 || rows > C2D_POLY_KMAX) return ~0ull;
 #pragma omp parallel for schedule(static) reduction(+ : count) reduction(| : bad)
     for (long long i = 0; i < (long long)n; i++) {
         float ax[C2D_POLY_KMAX], ay[C2D_POLY_KMAX], bx[C2D_POLY_KMAX], by[C2D_POLY_KMAX];
         int ka = k[i], kb = k[n + i];
-        if (ka < 1 || ka > C2D_POLY_KMAX || kb < 1 || kb > C2D_POLY_KMAX) { bad = 1; out[i] = 0; continue; }
+        if (ka < 1 || ka > rows || kb < 1 || kb > rows) { bad = 1; out[i] = 0; continue; }
         for (int v = 0; v < ka; v++) {
             ax[v] = vx[(size_t)v * n + i];
             ay[v] = vy[(size_t)v * n + i];
         }
         for (int v = 0; v < kb; v++) {
-            bx[v] = vx[((size_t)C2D_POLY_KMAX + v) * n + i];
-            by[v] = vy[((size_t)C2D_POLY_KMAX + v) * n + i];
+            bx[v] = vx[((size_t)rows + v) * n + i];
+            by[v] = vy[((size_t)rows + v) * n + i];
         }
         int c = c2d_oracle_poly_collide(ax, ay, ka, bx, by, kb);
         out[i] = (uint8_t)c;
         count += (unsigned)c;
     }
     return bad ? ~0ull : count;
+}
+
+unsigned long long c2d_oracle_sat_poly_pairs(const float* vx, const float* vy, const uint8_t* k,
+                                             size_t n, uint8_t* out)
+{
+    return c2d_oracle_sat_poly_pairs_rows(vx, vy, k, n, C2D_POLY_KMAX, out);
 }
 
 /* ------------------------------------------------------------------------ */

@@ -237,16 +237,19 @@ def sat_rect_pairs_pose(pp):
 
 
 def sat_poly_pairs(vx, vy, k):
-    """vx, vy: float32 [2][KMAX][n]; k: uint8 [2][n]"""
+    """vx, vy: float32 [2][rows][n] (rows = vertex rows per polygon, 1..KMAX); k: uint8 [2][n]"""
     vx, vy = _f32(vx), _f32(vy)
     k = np.ascontiguousarray(k, dtype=np.uint8)
     n = vx.shape[-1]
-    assert vx.shape == (2, KMAX, n) and k.shape == (2, n)
+    rows = vx.shape[1]
+    assert vx.shape == vy.shape == (2, rows, n) and 1 <= rows <= KMAX and k.shape == (2, n)
     out = np.empty(n, np.uint8)
-    cnt = lib().c2d_oracle_sat_poly_pairs(_ptr(vx), _ptr(vy), _ptr(k, C.c_uint8), C.c_size_t(n),
-                                          _ptr(out, C.c_uint8))
+    L = lib()
+    L.c2d_oracle_sat_poly_pairs_rows.restype = C.c_ulonglong
+    cnt = L.c2d_oracle_sat_poly_pairs_rows(_ptr(vx), _ptr(vy), _ptr(k, C.c_uint8), C.c_size_t(n), C.c_int(rows),
+                                           _ptr(out, C.c_uint8))
     if cnt == 2**64 - 1:
-        raise ValueError("vertex count outside 1..KMAX")
+        raise ValueError("vertex count outside 1..rows")
     return out, int(cnt)
 
 

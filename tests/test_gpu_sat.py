@@ -270,6 +270,34 @@ def test_poly_dense_scenes(eng, oracle, wl, n, kmin, kmax, extent):
     assert 0.2 < ref.mean() < 1.0
 
 
+@pytest.mark.parametrize("rows,kmin,kmax,n,extent", [(4, 3, 4, 100_003, 8.0), (4, 1, 4, 30_001, 0.6), (3, 3, 3, 5000, 1.0), (8, 3, 8, 100_003, 8.0),
+                                                     (8, 5, 8, 30_001, 0.8), (6, 3, 6, 20_000, 1.5), (12, 3, 12, 50_001, 2.0), (9, 9, 9, 777, 1.0),
+                                                     (16, 3, 16, 10_000, 1.0), (1, 1, 1, 200, 1.0)])
+def test_poly_row_layouts(eng, pkg, oracle, wl, rows, kmin, kmax, n, extent):
+    """c2d_sat_poly_pairs_rows: layouts with fewer than C2D_POLY_KMAX vertex rows per polygon run the kernel instances sized
+    for 4 / 8 / 16 slots (rows <= 4: eight pairs per wave in the full evaluation, rows <= 8: four); sparse and dense scenes."""
+    vx, vy, k = wl.random_convex_polygons(n, seed=rows * 1000 + n, kmin=kmin, kmax=kmax, extent=extent, rows=rows)
+    ref, ref_cnt = oracle.sat_poly_pairs(vx, vy, k)
+    dvx, dvy, dk = eng.to_device(vx), eng.to_device(vy), eng.to_device(k)
+    d_out, d_cnt = eng.zeros(n + 8, np.uint8), eng.zeros(1, np.uint64)
+    eng.sat_poly_pairs_rows(dvx, dvy, dk, n, rows, d_out, d_cnt)
+    out, cnt = d_out.get(), int(d_cnt.get()[0])
+    assert np.array_equal(out[:n], ref) and cnt == ref_cnt and not out[n:].any()
+    # a count above `rows` (but within KMAX) is an error of THIS layout
+    if rows < wl.KMAX:
+        k2 = k.copy()
+        k2[0, n // 2] = rows + 1
+        dk2 = eng.to_device(k2)
+        eng.sat_poly_pairs_rows(dvx, dvy, dk2, n, rows, d_out, None)
+        with pytest.raises(pkg.C2DError):
+            eng.synchronize()
+        dk2.free()
+    with pytest.raises(pkg.C2DError):
+        eng.sat_poly_pairs_rows(dvx, dvy, dk, n, 17, d_out, None)
+    for a in (dvx, dvy, dk, d_out, d_cnt):
+        a.free()
+
+
 def test_poly_padding_is_never_interpreted_and_orientation_is_free(eng, oracle, wl):
     """Slots at and beyond the vertex count may hold anything (NaN, inf, huge values); clockwise polygons
     (inward-pointing (-ey, ex)) must give the oracle's booleans as well."""
