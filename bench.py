@@ -524,7 +524,7 @@ def main() -> None:
         padded_gbs = 259 * npoly / (poly_ms * 1e-3) / 1e9
         poly_leg = {"metric": "poly_pair_tests_per_s", "value": npoly * world * preps / pel, "pairs_per_gpu": npoly, "reps": preps,
                     "ms_per_pass": pel / preps * 1e3, "kernel_ms": round(poly_ms, 5), "collide_rate": poly_collide,
-                    "roofline": {"bound": "hbm", "kernel": "sat_poly_kernel", "achieved": round(padded_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "roofline": {"bound": "hbm", "kernel": "sat_poly_kernel<16, 5, true>", "achieved": round(padded_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(padded_gbs / HBM_PEAK_GBS, 4),
                                  "algorithmic_bytes_per_launch": 259 * npoly,
                                  "bytes_note": "259 B/pair = the padded layout f32[2][16][n] x 2 + 2 count bytes + 1 result byte (SURVEY.md §8d); every "
