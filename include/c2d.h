@@ -39,7 +39,7 @@ extern "C" {
 #endif
 
 #define C2D_VERSION_MAJOR 0
-#define C2D_VERSION_MINOR 1
+#define C2D_VERSION_MINOR 2
 
 /* ---- status codes ------------------------------------------------------ */
 #define C2D_OK 0
