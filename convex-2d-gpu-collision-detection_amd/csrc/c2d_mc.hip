@@ -348,7 +348,10 @@ __global__ void mc_scenes_init_kernel(AdaptiveState* state, uint32_t n_scenes)
     *state = init;
 }
 
-__global__ __launch_bounds__(kMcBlock) void mc_scenes_advance_kernel(ScenesArgs A)
+// 6 waves per SIMD (80 VGPRs, two dwords spilled) instead of the 5 the compiler's 81 VGPRs allow: the certain-miss path is a
+// chain of dependent Philox multiplies, and the sixth wave is worth 5 % on the config-4 workload (806.7 -> 765.5 ms per
+// 4e6 data points) and 4 % on the reference-default batch; 8 waves (64 VGPRs, 17 dwords spilled) give nothing more.
+__global__ __launch_bounds__(kMcBlock, 6) void mc_scenes_advance_kernel(ScenesArgs A)
 {
     __shared__ WaveQueue s_queue[kWavesPerBlock];
     const uint32_t n_active = A.state->n_active;
