@@ -26,7 +26,9 @@
 
 namespace c2d {
 
-constexpr int kMcBlock = 256;
+// One wave per block: a multi-wave block keeps its LDS and its place until the slowest of its waves is done, and the
+// work items differ by 4x in cost (config-4 shard 765 -> 751 ms, reference-default batch 58.8 -> 57.2 ms against 256 threads).
+constexpr int kMcBlock = 64;
 constexpr int kWavesPerBlock = kMcBlock / 64;
 
 // Wave-uniform description of one scene (reference ccp.cu:119-133).
@@ -630,7 +632,7 @@ int c2d_mc_pair(c2d_ctx* ctx, float robot_w, float robot_h, const Position* pos,
     A.chunk = (uint32_t)chunk;
     const uint64_t n_chunks = (n_samples + chunk - 1) / chunk;
     uint64_t blocks = (n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
-    const uint64_t max_blocks = (uint64_t)ctx->prop.multiProcessorCount * 64;
+    const uint64_t max_blocks = (uint64_t)ctx->prop.multiProcessorCount * 256 / kWavesPerBlock;  // 256 waves per CU
     if (blocks > max_blocks) blocks = max_blocks;
     DeviceGuard g(ctx->device);
     hipLaunchKernelGGL(mc_pair_kernel, dim3((unsigned)blocks), dim3(kMcBlock), 0, (hipStream_t)stream, A, d_hits);
@@ -717,7 +719,7 @@ int c2d_mc_scenes(c2d_ctx* ctx, const c2d_mc_scenes_args* a, c2d_stream stream)
 
     // grids sized for the largest step (every scene active); later steps leave blocks idle
     uint64_t adv_blocks = (a->n_scenes * (uint64_t)1 + kWavesPerBlock - 1) / kWavesPerBlock;
-    const uint64_t adv_min = (uint64_t)cus * 8, adv_max = (uint64_t)cus * 64;
+    const uint64_t adv_min = (uint64_t)cus * 32 / kWavesPerBlock, adv_max = (uint64_t)cus * 256 / kWavesPerBlock;  // 32..256 waves per CU
     adv_blocks = adv_blocks < adv_min ? adv_min : (adv_blocks > adv_max ? adv_max : adv_blocks);
     uint64_t dec_blocks = (a->n_scenes + 255) / 256;
     const uint64_t dec_max = (uint64_t)cus * 4;
