@@ -196,6 +196,10 @@ C2D_DEV bool sample_collides(const Scene& sc, const float (&o)[8])
 #ifndef C2D_MC_PRETEST_HOLDOFF
 #define C2D_MC_PRETEST_HOLDOFF 3
 #endif
+#ifndef C2D_MC_ILP
+#define C2D_MC_ILP 2
+#endif
+[[maybe_unused]] constexpr int kIlp = C2D_MC_ILP;  // Philox blocks computed side by side on the far-scene path
 constexpr int kQueueSlots = 128;  // per wave: < 64 left over + at most 64 pushed per iteration
 
 // Per-wave queue of samples the centre pretest could not rule out.  A far or mid-range scene
@@ -215,47 +219,11 @@ C2D_DEV uint32_t wave_count_hits(const Scene& sc, uint64_t seed, uint64_t scene_
     uint32_t hits = 0;    // wave-uniform (scalar) accumulator
     uint32_t qn = 0;      // queued samples (wave-uniform)
     uint32_t dense = 0;   // iterations to evaluate in place after the pretest ruled nothing out
-    // one trip beyond the last samples flushes what is left in the queue
-    for (uint32_t off = 0; off < count + 64; off += 64) {
-        const bool flush = off >= count;
-        if (!flush) {
-            const uint32_t idx = off + lane;
-            const bool in_range = idx < count;
-            const U4 a = philox_block(seed, scene_id, begin + idx, 0);
-            // radius-only pretest: every in-range lane's radius word already proves a miss
-#ifndef C2D_MC_NO_PRETEST  // validation builds evaluate every sample in full
-            if (sc.use_x0 && dense == 0 && __ballot(in_range && a.x < sc.x0) == 0ull) continue;
-#endif
-            float dx, dy;
-            sample_centre(sc, a, dx, dy);
-            if (dense) {  // near scene: every lane needs the full evaluation anyway
-                dense--;
-                float o[8];
-                sample_obstacle(sc, a.z, a.w, dx, dy, seed, scene_id, begin + idx, o);
-                hits += (uint32_t)__popcll(__ballot(sample_collides(sc, o) && in_range));
-                continue;
-            }
-#ifdef C2D_MC_NO_PRETEST
-            const bool undecided = in_range;
-#else
-            const bool undecided = in_range && !centre_pretest(sc, dx, dy);
-#endif
-            const unsigned long long m = __ballot(undecided);
-            if (m == 0ull) continue;  // the common case of a far scene: 64 certain misses
-            if (m == ~0ull) dense = C2D_MC_PRETEST_HOLDOFF;
-            if (undecided) {
-                const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                q.cw[pos] = make_float4(dx, dy, __uint_as_float(a.z), __uint_as_float(a.w));
-                q.idx[pos] = idx;
-            }
-            qn += (uint32_t)__popcll(m);
-            if (qn < 64) continue;
-        } else if (qn == 0) {
-            break;
-        }
-        // evaluate 64 queued samples (the last qn on the flush trip).  Lanes read slots that other lanes of
-        // this wave wrote: LDS operations of a wave complete in order, the fence pair only stops the compiler
-        // from reordering the reads above the writes (no instruction is emitted)
+
+    // evaluate 64 queued samples (the last qn on the flush trip).  Lanes read slots that other lanes of this wave
+    // wrote: LDS operations of a wave complete in order, the fence pairs only stop the compiler from reordering the
+    // reads above the writes and later writes above the reads (no instruction is emitted)
+    auto drain64 = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -264,14 +232,69 @@ C2D_DEV uint32_t wave_count_hits(const Scene& sc, uint64_t seed, uint64_t scene_
         const uint32_t src = qn - take + (live ? lane : 0);
         const float4 e = q.cw[src];
         const uint32_t eidx = q.idx[src];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // later queue writes stay behind these reads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         qn -= take;
         float o[8];
         sample_obstacle(sc, __float_as_uint(e.z), __float_as_uint(e.w), e.x, e.y, seed, scene_id, begin + eidx, o);
         hits += (uint32_t)__popcll(__ballot(sample_collides(sc, o) && live));
+    };
+    // one iteration's 64 samples, given their first Philox block, from the obstacle centre on
+    auto process = [&](uint32_t idx, bool in_range, const U4& a) {
+        float dx, dy;
+        sample_centre(sc, a, dx, dy);
+        if (dense) {  // near scene: every lane needs the full evaluation anyway
+            dense--;
+            float o[8];
+            sample_obstacle(sc, a.z, a.w, dx, dy, seed, scene_id, begin + idx, o);
+            hits += (uint32_t)__popcll(__ballot(sample_collides(sc, o) && in_range));
+            return;
+        }
+#ifdef C2D_MC_NO_PRETEST
+        const bool undecided = in_range;
+#else
+        const bool undecided = in_range && !centre_pretest(sc, dx, dy);
+#endif
+        const unsigned long long m = __ballot(undecided);
+        if (m == 0ull) return;  // the common case of a far scene: 64 certain misses
+        if (m == ~0ull) dense = C2D_MC_PRETEST_HOLDOFF;
+        if (undecided) {
+            const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            q.cw[pos] = make_float4(dx, dy, __uint_as_float(a.z), __uint_as_float(a.w));
+            q.idx[pos] = idx;
+        }
+        qn += (uint32_t)__popcll(m);
+        if (qn >= 64) drain64();
+    };
+
+    uint32_t off = 0;
+    while (off < count) {
+#ifndef C2D_MC_NO_PRETEST  // validation builds evaluate every sample in full
+        // Far scene (the radius word alone can prove a miss): kIlp iterations' Philox blocks are computed side by side —
+        // independent multiply chains per lane instead of one — and an iteration whose 64 radius words all prove
+        // a miss costs nothing beyond them.
+        if (sc.use_x0 && dense == 0 && off + 64 * kIlp <= count) {
+            U4 a[kIlp];
+#pragma unroll
+            for (int b = 0; b < kIlp; b++) a[b] = philox_block(seed, scene_id, begin + off + 64 * b + lane, 0);
+#pragma unroll
+            for (int b = 0; b < kIlp; b++)
+                if (__ballot(a[b].x < sc.x0) != 0ull) process(off + 64 * b + lane, true, a[b]);
+            off += 64 * kIlp;
+            continue;
+        }
+#endif
+        const uint32_t idx = off + lane;
+        const bool in_range = idx < count;
+        const U4 a = philox_block(seed, scene_id, begin + idx, 0);
+        off += 64;
+#ifndef C2D_MC_NO_PRETEST
+        if (sc.use_x0 && dense == 0 && __ballot(in_range && a.x < sc.x0) == 0ull) continue;
+#endif
+        process(idx, in_range, a);
     }
+    while (qn) drain64();  // what is left in the queue
     return hits;
 }
 
