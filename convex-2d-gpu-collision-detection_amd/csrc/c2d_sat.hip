@@ -138,47 +138,66 @@ __global__ __launch_bounds__(kBlock) void sat_rect_verts_mask1_kernel(Planes16 P
 // float[8] rectangles (utils.cu:159), batched: r1, r2 are f32[n][8].  A lane reads its
 // pair as 4 x 16 B; a wave covers 2 x 2 KiB of contiguous memory, so the loads coalesce
 // as well as the SoA planes do (same 65 B/pair).
-__global__ __launch_bounds__(kBlock) void sat_rect_aos_kernel(const float* __restrict__ r1s, const float* __restrict__ r2s,
-                                                              size_t n, uint8_t* __restrict__ out,
-                                                              unsigned long long* __restrict__ d_count,
-                                                              unsigned long long* __restrict__ words)
+template <bool OUT16>
+__global__ __launch_bounds__(64) void sat_rect_aos_kernel(const float* __restrict__ r1s, const float* __restrict__ r2s,
+                                                         size_t n, uint8_t* __restrict__ out,
+                                                         unsigned long long* __restrict__ d_count,
+                                                         unsigned long long* __restrict__ words)
 {
-    // A wave owns 64 consecutive pairs = 2 KiB of r1 and 2 KiB of r2.  Lane i fetches the 16-byte
-    // chunks i and 64 + i of each (two fully coalesced 1-KiB loads per array), the chunks go through
-    // a wave-private LDS tile, and lane p reads back its own pair (chunks 2p, 2p + 1).  Loading a
-    // lane's 32 bytes directly (stride-32 16-byte loads) touches every cache line twice: 120 vs 104 us.
-    __shared__ __attribute__((aligned(16))) f32x4 tile[kBlock / 64][2][128];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // A wave owns 128 consecutive pairs = 4 KiB of r1 and 4 KiB of r2.  Lane i fetches the 16-byte chunks i, 64 + i,
+    // 128 + i and 192 + i of each array (eight fully coalesced 1-KiB loads in flight per lane), the chunks go through a
+    // wave-private LDS tile, and lane p reads back its own two pairs 2p, 2p + 1 (chunks 4p .. 4p + 3) and stores both
+    // result bytes at once.  Loading a lane's bytes directly (strided 16-byte loads) touches every cache line twice:
+    // 120 vs 104 us.  One wave per block, no grid-stride loop, as for the plane-format kernel.
+    constexpr int kChunks = 256;  // 16-byte chunks per array and tile
+    __shared__ __attribute__((aligned(16))) f32x4 tile[2][kChunks];
+    const int lane = threadIdx.x;
     uint32_t my_count = 0;
-    const size_t n_tiles = (n + 63) / 64;
-    const size_t tiles_per_pass = (size_t)gridDim.x * (kBlock / 64);
-    for (size_t t = (size_t)blockIdx.x * (kBlock / 64) + wave; t < n_tiles; t += tiles_per_pass) {
-        const size_t p0 = t * 64;
-        const size_t chunks = (n - p0 < 64 ? n - p0 : 64) * 2;  // 16-byte chunks of this tile per array
+    const size_t n_tiles = (n + 127) / 128;
+    for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const size_t p0 = t * 128;
+        const size_t chunks = (n - p0 < 128 ? n - p0 : 128) * 2;  // 16-byte chunks of this tile per array
         const f32x4* a = reinterpret_cast<const f32x4*>(r1s) + 2 * p0;
         const f32x4* b = reinterpret_cast<const f32x4*>(r2s) + 2 * p0;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 a_lo = (size_t)lane < chunks ? __builtin_nontemporal_load(a + lane) : zero;
-        const f32x4 a_hi = (size_t)(64 + lane) < chunks ? __builtin_nontemporal_load(a + 64 + lane) : zero;
-        const f32x4 b_lo = (size_t)lane < chunks ? __builtin_nontemporal_load(b + lane) : zero;
-        const f32x4 b_hi = (size_t)(64 + lane) < chunks ? __builtin_nontemporal_load(b + 64 + lane) : zero;
-        tile[wave][0][lane] = a_lo;
-        tile[wave][0][64 + lane] = a_hi;
-        tile[wave][1][lane] = b_lo;
-        tile[wave][1][64 + lane] = b_hi;
+        f32x4 va[4], vb[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const size_t c = (size_t)(64 * k + lane);
+            va[k] = c < chunks ? __builtin_nontemporal_load(a + c) : zero;
+            vb[k] = c < chunks ? __builtin_nontemporal_load(b + c) : zero;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            tile[0][64 * k + lane] = va[k];
+            tile[1][64 * k + lane] = vb[k];
+        }
         // same wave wrote and reads: LDS operations of a wave complete in order; the fence pair keeps the
         // compiler from moving a lane's reads above another lane's writes (it emits no instruction)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const f32x4 a0 = tile[wave][0][2 * lane], a1 = tile[wave][0][2 * lane + 1];
-        const f32x4 b0 = tile[wave][1][2 * lane], b1 = tile[wave][1][2 * lane + 1];
-        const float r1[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-        const float r2[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-        const uint32_t c = rect_collide(r1, r2) ? 1u : 0u;
-        if (p0 + lane < n) {
-            out[p0 + lane] = (uint8_t)c;
-            my_count += c;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const f32x4 a0 = tile[0][4 * lane + 2 * e], a1 = tile[0][4 * lane + 2 * e + 1];
+            const f32x4 b0 = tile[1][4 * lane + 2 * e], b1 = tile[1][4 * lane + 2 * e + 1];
+            const float r1[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            const float r2[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            packed |= (rect_collide(r1, r2) ? 1u : 0u) << (8 * e);
+        }
+        const size_t i = p0 + 2 * (size_t)lane;
+        if (i + 1 < n) {
+            if constexpr (OUT16) {
+                *reinterpret_cast<uint16_t*>(out + i) = (uint16_t)packed;  // i is even and `out` 2-byte aligned
+            } else {
+                out[i] = (uint8_t)(packed & 1u);
+                out[i + 1] = (uint8_t)(packed >> 8);
+            }
+            my_count += (uint32_t)__popc(packed);
+        } else if (i < n) {
+            out[i] = (uint8_t)(packed & 1u);
+            my_count += packed & 1u;
         }
         // the next tile's stores must not overtake this tile's loads
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -409,9 +428,11 @@ int c2d_sat_rect_pairs_aos(c2d_ctx* ctx, const float* d_r1, const float* d_r2, s
     if (!aligned_to(d_r1, 16) || !aligned_to(d_r2, 16)) return fail_arg(ctx, "c2d_sat_rect_pairs_aos: rectangle arrays must be 16-byte aligned");
     DeviceGuard g(ctx->device);
     if (int rc = workspace_acquire(ctx, (hipStream_t)stream, d_count != nullptr)) return rc;
-    const int grid = grid_for(n, kBlock, kMaxBlocks);  // one 64-pair tile per wave
-    hipLaunchKernelGGL(sat_rect_aos_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, d_r1, d_r2, n, d_out, d_count,
-                       ctx->d_count_words);
+    const int grid = grid_for(n, 128, kMaxBlocks);  // one 128-pair tile per single-wave block
+    if (aligned_to(d_out, 2))
+        hipLaunchKernelGGL(sat_rect_aos_kernel<true>, dim3(grid), dim3(64), 0, (hipStream_t)stream, d_r1, d_r2, n, d_out, d_count, ctx->d_count_words);
+    else
+        hipLaunchKernelGGL(sat_rect_aos_kernel<false>, dim3(grid), dim3(64), 0, (hipStream_t)stream, d_r1, d_r2, n, d_out, d_count, ctx->d_count_words);
     C2D_LAUNCH_CHECK(ctx);
     workspace_release(ctx, (hipStream_t)stream, d_count != nullptr);
     return C2D_OK;

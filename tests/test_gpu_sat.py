@@ -102,16 +102,19 @@ def test_random_1m_verts_and_pose_paths(eng, oracle, wl):
     assert np.array_equal(ref_pose, ref)
 
 
-@pytest.mark.parametrize("n", [1, 255, 100_003])
-def test_aos_layout_matches_planes(eng, oracle, wl, n):
-    """convex_collide's own layout: float[8] per rectangle, f32[n][8] arrays."""
+@pytest.mark.parametrize("n,out_offset", [(1, 0), (2, 0), (126, 0), (127, 0), (128, 0), (129, 0), (255, 0), (257, 1), (100_003, 0), (100_004, 1)])
+def test_aos_layout_matches_planes(eng, oracle, wl, n, out_offset):
+    """convex_collide's own layout: float[8] per rectangle, f32[n][8] arrays; 128-pair tiles with ragged ends; an
+    odd-aligned output buffer takes the byte-store instance."""
     poses = wl.random_obb_pose_planes(n, seed=300 + n, extent=3.0)
     r1, r2 = oracle.rects_from_poses(*poses[:5]), oracle.rects_from_poses(*poses[5:])
     ref, ref_cnt = oracle.sat_rect_pairs_verts(np.concatenate([r1, r2]))
     d1, d2 = eng.to_device(np.ascontiguousarray(r1.T)), eng.to_device(np.ascontiguousarray(r2.T))
     d_out, d_cnt = eng.zeros(n + 8, np.uint8), eng.zeros(1, np.uint64)
-    eng.sat_rect_pairs_aos(d1, d2, n, d_out, d_cnt)
+    eng.sat_rect_pairs_aos(d1, d2, n, d_out.ptr + out_offset, d_cnt)
     out = d_out.get()
+    assert not out[:out_offset].any()
+    out = out[out_offset:]
     assert np.array_equal(out[:n], ref) and not out[n:].any() and int(d_cnt.get()[0]) == ref_cnt
     for i in range(min(n, 5)):
         assert oracle.convex_collide(r1[:, i], r2[:, i]) == ref[i]
