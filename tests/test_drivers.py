@@ -56,6 +56,17 @@ def test_multi_rank_flags_are_checked_before_any_gpu_work(tmp_path):
 
 
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="CPU-only behaviour")
+def test_self_launched_ranks_propagate_failure_without_gpu(tmp_path):
+    """--gpus N: the launcher starts N fresh copies of itself and returns the first non-zero exit status; without a GPU every
+    rank fails loudly at c2d_ctx_create, and so does the launcher."""
+    out = run([GEN, "--data_dir", str(tmp_path / "d"), "--gpus", "2", "-n", "2", "-b", "10", "--num_poses", "10", "--num_variances", "10"])
+    assert out.returncode != 0 and out.stderr.count("no usable device") == 2
+    out = run([CCP, "--pair_samples", "1000", "--gpus", "3"])
+    assert out.returncode != 0 and out.stderr.count("no usable device") == 3
+    assert not list(tmp_path.glob("c2d_dist_id_*"))
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="CPU-only behaviour")
 def test_generate_dataset_writes_tables_then_fails_loudly_without_gpu(tmp_path):
     d = tmp_path / "data"
     out = run([GEN, "--data_dir", str(d), "-n", "1", "-b", "100", "--num_poses", "1000", "--num_variances", "500",
