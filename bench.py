@@ -85,16 +85,16 @@ def self_launch(n_gpus: int) -> int:
     return 0 if line is not None else 1
 
 
-def torch_random_convex_polygons(torch, dev, n, seed, kmin=3, kmax=KMAX, extent=8.0):
-    """Device-side twin of workloads.random_convex_polygons (config 5 input)."""
+def torch_random_convex_polygons(torch, dev, n, seed, kmin=3, kmax=KMAX, extent=8.0, rows=KMAX):
+    """Device-side twin of workloads.random_convex_polygons (config 5 input); rows = vertex rows per polygon of the layout."""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
-    vx = torch.zeros((2, KMAX, n), dtype=torch.float32, device=dev)
+    vx = torch.zeros((2, rows, n), dtype=torch.float32, device=dev)
     vy = torch.zeros_like(vx)
     k = torch.randint(kmin, kmax + 1, (2, n), generator=g, device=dev, dtype=torch.int32)
     for p in range(2):
-        mask = torch.arange(KMAX, device=dev)[:, None] >= k[p][None, :]
-        ang = torch.rand((KMAX, n), generator=g, device=dev) * (2 * np.pi)
+        mask = torch.arange(rows, device=dev)[:, None] >= k[p][None, :]
+        ang = torch.rand((rows, n), generator=g, device=dev) * (2 * np.pi)
         ang[mask] = float("inf")
         ang, _ = torch.sort(ang, dim=0)
         ang[mask] = 0
@@ -541,7 +541,31 @@ def main() -> None:
             if c.get("hbm_bytes_per_launch"):
                 poly_leg["roofline"]["traffic"] = c["hbm_bytes_per_launch"]
                 poly_leg["roofline"]["traffic_source"] = "recorded, not measured in this run: %s" % c.get("source")
-        del vx, vy, kk, pout
+        del vx, vy, kk
+
+        # the same entry point on a tight layout of small polygons (triangles and quadrilaterals, 4 vertex rows: 67 B/pair)
+        vx4, vy4, kk4 = torch_random_convex_polygons(torch, dev, npoly, seed=0xBEEF + rank, kmin=3, kmax=4, rows=4)
+        torch.cuda.synchronize()
+
+        def small_step():
+            eng.sat_poly_pairs_rows(vx4.data_ptr(), vy4.data_ptr(), kk4.data_ptr(), npoly, 4, pout.data_ptr(), None, stream=sh)
+
+        prewarm(small_step)
+        r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        r0.record(stream)
+        for _ in range(preps):
+            small_step()
+        r1.record(stream)
+        torch.cuda.synchronize()
+        eng.check_async()
+        sms = r0.elapsed_time(r1) / preps
+        sgbs = 67 * npoly / (sms * 1e-3) / 1e9
+        poly_leg["small_polygons"] = {"metric": "poly_pair_tests_per_s (K ~ U{3..4}, 4-row layout, per GPU)", "value": npoly / (sms * 1e-3),
+                                      "kernel_ms": round(sms, 5), "collide_rate": float(pout.to(torch.int64).sum().item()) / npoly,
+                                      "roofline": {"bound": "hbm", "kernel": "sat_poly_kernel<4, 8, false>", "achieved": round(sgbs, 1),
+                                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(sgbs / HBM_PEAK_GBS, 4),
+                                                   "algorithmic_bytes_per_launch": 67 * npoly, "traffic": None}}
+        del vx4, vy4, kk4, pout
 
     # ---- CPU baseline: oracle port on this host, rank 0, N = 1 only ------------------------------
     cpu_baseline = None
