@@ -337,7 +337,7 @@ struct AdaptiveState {
     uint32_t ticket;       // blocks of the decide step that have finished
     uint32_t list_sel;     // which list holds the active indices
     uint32_t identity;     // 1: the active list is 0..n_active-1 (first step)
-    uint32_t pad;
+    uint32_t burst_steps;  // scratch of the burst's decide step: most steps any scene of the burst needed
     unsigned long long total_samples;
 };
 
@@ -352,6 +352,33 @@ C2D_DEV uint32_t batch_of(const ScheduleArgs& S, uint32_t n_samples)
     return n_samples < S.switch_at ? S.small_batch : S.large_batch;  // ccp.cu:283-286
 }
 
+// calcSlack (reference utils.cu:186-196), int overflow D1 fixed
+C2D_DEV float calc_slack(uint32_t n, uint32_t k)
+{
+    if (k == n || k == 0) {
+        // log(1.0 / (double)0.025f) / n, evaluated in double as in the reference
+        return (float)(0x1.d82d33932720dp+1 / (double)n);
+    }
+    const float z = 1.96f;
+    const float kf = (float)k;
+    const float kk = (float)((uint64_t)k * (uint64_t)k);
+    return z / (float)n * __builtin_sqrtf(kf - kk / (float)n);
+}
+
+// getBin (reference utils.cu:198-207), out-of-bounds read D2 fixed
+C2D_DEV int get_bin(float p, const float* bins, uint32_t n_bins)
+{
+    int bin = 0;
+    for (uint32_t i = 0; i + 1 < n_bins; i++)
+        if (p >= bins[i] && p <= bins[i + 1]) bin = (int)i;
+    return bin;
+}
+
+// Burst: the leading small-batch steps of the schedule (20 x 1000 samples by default) are run by ONE launch.  During
+// those steps a scene is one work item anyway (its batch is smaller than the smallest chunk), so the wave that owns a scene
+// simply goes on: batch, stop test of ccp.cu:140-148 on its own hit count, next batch ... until the test passes or the
+// burst ends.  Results are the same numbers as step-by-step — the stop rule of a scene only ever looks at that scene —
+// but the scene is set up once instead of once per step and 2 x (B - 1) kernel boundaries disappear.
 struct ScenesArgs {
     const Pose* poses;
     const StdDev* std_devs;
@@ -363,6 +390,12 @@ struct ScenesArgs {
     uint64_t seed, scene_id_base;
     ScheduleArgs sched;
     uint32_t* hits;           // u32[n_scenes], accumulated
+    // burst mode (first launch only; burst_steps <= 1: off)
+    uint32_t burst_steps;
+    uint32_t n_bins;
+    float bins[16], acc[16];
+    uint32_t* n_used;
+    PoseCPVarAndPoseIdx* rows;  // may be NULL
 };
 
 __global__ void mc_scenes_init_kernel(AdaptiveState* state, uint32_t n_scenes)
@@ -395,6 +428,38 @@ __global__ __launch_bounds__(kMcBlock, 6) void mc_scenes_advance_kernel(ScenesAr
     wps = (n_batch + chunk - 1) / chunk;
 
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (A.burst_steps > 1) {  // first launch of a call: n_start == 0, identity list, one work item per scene
+        for (uint64_t item = (uint64_t)blockIdx.x * kWavesPerBlock + wave; item < n_active; item += (uint64_t)gridDim.x * kWavesPerBlock) {
+            const uint32_t g = (uint32_t)item;
+            const PositionWithVarAndPoseIdx row = A.scenes[g];
+            uint32_t pi = (uint32_t)(int)row.pose_idx, vi = (uint32_t)(int)row.var_idx;
+            pi = pi < A.num_poses ? pi : A.num_poses - 1;
+            vi = vi < A.num_std_devs ? vi : A.num_std_devs - 1;
+            const Scene sc = make_scene(A.robot_w, A.robot_h, row.x, row.y, A.poses[pi], A.std_devs[vi]);
+            uint32_t k = 0, n = 0;
+            float p = 0.0f;
+            bool done = false;
+            for (uint32_t b = 0; b < A.burst_steps && !done; b++) {
+                k += wave_count_hits(sc, A.seed, A.scene_id_base + g, (uint64_t)n, n_batch, s_queue[wave]);
+                n += n_batch;
+                const float slack = calc_slack(n, k);                                       // ccp.cu:140
+                p = (float)k / (float)n;                                                    // ccp.cu:142
+                done = slack <= A.acc[get_bin(p, A.bins, A.n_bins)] || n >= A.sched.max_samples;  // ccp.cu:144, :281
+            }
+            if ((threadIdx.x & 63) == 0) {
+                A.hits[g] = k;
+                if (done) {  // finished inside the burst; the burst's decide step recognises it by n_used != 0
+                    A.n_used[g] = n;
+                    if (A.rows) {
+                        PoseCPVarAndPoseIdx o;
+                        o.x = row.x; o.y = row.y; o.cp = p; o.var_idx = row.var_idx; o.pose_idx = row.pose_idx;
+                        A.rows[g] = o;
+                    }
+                }
+            }
+        }
+        return;
+    }
     const uint64_t n_items = (uint64_t)n_active * wps;
     for (uint64_t item = (uint64_t)blockIdx.x * kWavesPerBlock + wave; item < n_items;
          item += (uint64_t)gridDim.x * kWavesPerBlock) {
@@ -417,28 +482,6 @@ __global__ __launch_bounds__(kMcBlock, 6) void mc_scenes_advance_kernel(ScenesAr
     }
 }
 
-// calcSlack (reference utils.cu:186-196), int overflow D1 fixed
-C2D_DEV float calc_slack(uint32_t n, uint32_t k)
-{
-    if (k == n || k == 0) {
-        // log(1.0 / (double)0.025f) / n, evaluated in double as in the reference
-        return (float)(0x1.d82d33932720dp+1 / (double)n);
-    }
-    const float z = 1.96f;
-    const float kf = (float)k;
-    const float kk = (float)((uint64_t)k * (uint64_t)k);
-    return z / (float)n * __builtin_sqrtf(kf - kk / (float)n);
-}
-
-// getBin (reference utils.cu:198-207), out-of-bounds read D2 fixed
-C2D_DEV int get_bin(float p, const float* bins, uint32_t n_bins)
-{
-    int bin = 0;
-    for (uint32_t i = 0; i + 1 < n_bins; i++)
-        if (p >= bins[i] && p <= bins[i + 1]) bin = (int)i;
-    return bin;
-}
-
 // After a batch: stop test of ccp.cu:140-148 per active scene, compaction of the
 // survivors into the other list (replaces thrust::count + sort_by_key,
 // ccp.cu:307-311), write_collision_probability (utils.cu:210-215) for the
@@ -455,6 +498,7 @@ struct DecideArgs {
     const uint32_t* hits;
     uint32_t* n_used;
     PoseCPVarAndPoseIdx* rows;  // may be NULL
+    uint32_t burst_steps;       // > 1: this is the decide step of a burst (the waves already applied the stop rule)
 };
 
 __global__ __launch_bounds__(256) void mc_scenes_decide_kernel(DecideArgs A)
@@ -464,11 +508,14 @@ __global__ __launch_bounds__(256) void mc_scenes_decide_kernel(DecideArgs A)
     const uint32_t n_start = A.state->n_samples;
     if (n_start >= A.sched.max_samples) return;
     const uint32_t n_batch = batch_of(A.sched, n_start);
-    const uint32_t n = n_start + n_batch;
+    const bool burst = A.burst_steps > 1;
+    const uint32_t n = n_start + (burst ? A.burst_steps * n_batch : n_batch);
     const bool identity = A.state->identity != 0;
     const uint32_t sel = A.state->list_sel;
     const uint32_t* active = identity ? nullptr : A.lists[sel];
     uint32_t* next = A.lists[identity ? 0 : (sel ^ 1u)];
+    unsigned long long drawn = 0;   // burst: samples this thread's scenes drew
+    uint32_t max_steps = 0;
     __shared__ float s_bins[16], s_acc[16];
     if (threadIdx.x < 16) { s_bins[threadIdx.x] = A.bins[threadIdx.x]; s_acc[threadIdx.x] = A.acc[threadIdx.x]; }
     __syncthreads();
@@ -478,7 +525,15 @@ __global__ __launch_bounds__(256) void mc_scenes_decide_kernel(DecideArgs A)
         const uint32_t slot = (r * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
         bool survive = false;
         uint32_t g = 0;
-        if (slot < n_active) {
+        if (slot < n_active && burst) {
+            g = active ? active[slot] : slot;
+            const uint32_t nu = A.n_used[g];   // != 0: the scene's wave found its stop test passing after nu samples
+            survive = nu == 0;
+            const uint32_t n_g = survive ? n : nu;
+            drawn += n_g - n_start;
+            const uint32_t steps_g = (n_g - n_start) / n_batch;
+            max_steps = steps_g > max_steps ? steps_g : max_steps;
+        } else if (slot < n_active) {
             g = active ? active[slot] : slot;
             const uint32_t k = A.hits[g];
             const float slack = calc_slack(n, k);                         // ccp.cu:140
@@ -509,16 +564,28 @@ __global__ __launch_bounds__(256) void mc_scenes_decide_kernel(DecideArgs A)
     // The block whose ticket is the last one rolls the state.  Every append above is a
     // returning device-scope atomic that has completed, and the fence orders this block's
     // list stores before its ticket; the next kernel starts behind the kernel boundary.
+    if (burst) {  // wave-reduced: samples drawn and the largest number of steps any scene needed
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            drawn += __shfl_down(drawn, off, 64);
+            const uint32_t o = (uint32_t)__shfl_down((int)max_steps, off, 64);
+            max_steps = o > max_steps ? o : max_steps;
+        }
+        if ((threadIdx.x & 63) == 0 && drawn) {
+            atomicAdd(&A.state->total_samples, drawn);
+            atomicMax(&A.state->burst_steps, max_steps);
+        }
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
         const uint32_t t = atomicAdd(&A.state->ticket, 1u);
         if (t == gridDim.x - 1) {
             const uint32_t survivors = atomicExch(&A.state->next_count, 0u);
-            A.state->total_samples += (unsigned long long)n_active * n_batch;
+            if (!burst) A.state->total_samples += (unsigned long long)n_active * n_batch;
             A.state->n_active = survivors;
             A.state->n_samples = n;
-            A.state->iter += 1;
+            A.state->iter += burst ? atomicExch(&A.state->burst_steps, 0u) : 1u;
             A.state->ticket = 0;
             A.state->list_sel = identity ? 0u : (sel ^ 1u);
             A.state->identity = 0;
@@ -723,6 +790,11 @@ int c2d_mc_scenes(c2d_ctx* ctx, const c2d_mc_scenes_args* a, c2d_stream stream)
 
     hipLaunchKernelGGL(mc_scenes_init_kernel, dim3(1), dim3(1), 0, s, d_state, (uint32_t)a->n_scenes);
     C2D_HIP(ctx, hipMemsetAsync(a->d_hits, 0, a->n_scenes * sizeof(uint32_t), s));
+    // Burst: the leading steps that all use the small batch, when that batch is one work item per scene anyway
+    uint32_t burst = 0;
+    if (S.small_batch <= S.min_chunk)
+        for (uint64_t ns = 0; ns < a->max_samples && ns < S.switch_at; ns += S.small_batch) burst++;
+    if (burst > 1) C2D_HIP(ctx, hipMemsetAsync(a->d_n_used, 0, a->n_scenes * sizeof(uint32_t), s));  // n_used != 0 marks "finished in the burst"
 
     ScenesArgs A;
     A.poses = a->d_poses; A.std_devs = a->d_std_devs; A.scenes = a->d_scenes;
@@ -731,14 +803,15 @@ int c2d_mc_scenes(c2d_ctx* ctx, const c2d_mc_scenes_args* a, c2d_stream stream)
     A.robot_w = a->robot_w; A.robot_h = a->robot_h;
     A.seed = a->seed; A.scene_id_base = a->scene_id_base;
     A.sched = S; A.hits = a->d_hits;
+    A.burst_steps = 0; A.n_bins = a->n_accuracy_bins; A.n_used = a->d_n_used; A.rows = a->d_rows;
     DecideArgs D;
     D.scenes = a->d_scenes; D.state = d_state; D.lists[0] = ctx->d_list[0]; D.lists[1] = ctx->d_list[1];
     D.sched = S; D.n_bins = a->n_accuracy_bins;
     for (uint32_t i = 0; i < 16; i++) {
-        D.bins[i] = i < a->n_accuracy_bins ? a->accuracy_bins[i] : 0.0f;
-        D.acc[i] = i + 1 < a->n_accuracy_bins ? a->bin_accuracy[i] : 0.0f;
+        D.bins[i] = A.bins[i] = i < a->n_accuracy_bins ? a->accuracy_bins[i] : 0.0f;
+        D.acc[i] = A.acc[i] = i + 1 < a->n_accuracy_bins ? a->bin_accuracy[i] : 0.0f;
     }
-    D.hits = a->d_hits; D.n_used = a->d_n_used; D.rows = a->d_rows;
+    D.hits = a->d_hits; D.n_used = a->d_n_used; D.rows = a->d_rows; D.burst_steps = 0;
 
     // grids sized for the largest step (every scene active); later steps leave blocks idle
     uint64_t adv_blocks = (a->n_scenes * (uint64_t)1 + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -747,7 +820,16 @@ int c2d_mc_scenes(c2d_ctx* ctx, const c2d_mc_scenes_args* a, c2d_stream stream)
     uint64_t dec_blocks = (a->n_scenes + 255) / 256;
     const uint64_t dec_max = (uint64_t)cus * 4;
     dec_blocks = dec_blocks > dec_max ? dec_max : dec_blocks;
-    for (uint32_t it = 0; it < steps; it++) {
+    uint32_t it = 0;
+    if (burst > 1) {  // steps 0 .. burst-1 in one advance / decide pair
+        ScenesArgs AB = A;
+        DecideArgs DB = D;
+        AB.burst_steps = DB.burst_steps = burst;
+        hipLaunchKernelGGL(mc_scenes_advance_kernel, dim3((unsigned)adv_blocks), dim3(kMcBlock), 0, s, AB);
+        hipLaunchKernelGGL(mc_scenes_decide_kernel, dim3((unsigned)dec_blocks), dim3(256), 0, s, DB);
+        it = burst;
+    }
+    for (; it < steps; it++) {
         hipLaunchKernelGGL(mc_scenes_advance_kernel, dim3((unsigned)adv_blocks), dim3(kMcBlock), 0, s, A);
         hipLaunchKernelGGL(mc_scenes_decide_kernel, dim3((unsigned)dec_blocks), dim3(256), 0, s, D);
     }
