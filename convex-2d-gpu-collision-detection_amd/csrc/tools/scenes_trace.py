@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-step trace of the adaptive Monte-Carlo loop on the reference-default batch (VERDICT r1
-item 7): 1e5 scenes, max_samples 4 000 000 => 60 schedule steps (20 x 1000 samples, then 40 x 100 000).
+item 7): 1e5 scenes, max_samples 4 000 000 => 60 schedule steps (20 x 1000 samples — run as one launch —, then 40 x 100 000).
 
   scenes_trace.py run <out_dir>            runs the batch (twice: warm-up, then the traced run) and saves n_used;
                                             put it under `rocprofv3 --kernel-trace --output-format csv -d <trace_dir> -- python3 ...`
@@ -61,16 +61,20 @@ def digest(trace_dir, out_dir):
     rows = [r for r in csv.DictReader(open(f)) if "mc_scenes_advance_kernel" in r["Kernel_Name"] or "mc_scenes_decide_kernel" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     steps = schedule()
-    rows = rows[-2 * len(steps):]                      # the last call
+    # the leading small-batch steps (batch <= 1024 samples) run as ONE advance / decide pair (the "burst", c2d_mc.hip)
+    burst = sum(1 for n0, b in steps if b <= 1024 and n0 < 20000)
+    burst = burst if burst > 1 else 0
+    groups = ([steps[:burst]] if burst else []) + [[st] for st in steps[burst:]]
+    rows = rows[-2 * len(groups):]                     # the last call
     used = np.load(os.path.join(out_dir, "n_used.npy")).astype(np.int64)
     print(open(os.path.join(out_dir, "run.txt")).read().strip())
     print()
-    print("| step | samples before | batch | active scenes | advance us | decide us | gap before advance us | samples this step | 1e9 samples/s |")
+    print("| steps | samples before | batch | active scenes at the first step | advance us | decide us | gaps us | samples drawn | 1e9 samples/s |")
     print("|---|---|---|---|---|---|---|---|---|")
     t_first = int(rows[0]["Start_Timestamp"])
     prev_end = None
     tot_adv = tot_dec = tot_gap = 0.0
-    for i, (n0, b) in enumerate(steps):
+    for i, grp in enumerate(groups):
         adv, dec = rows[2 * i], rows[2 * i + 1]
         assert "advance" in adv["Kernel_Name"] and "decide" in dec["Kernel_Name"]
         a_us = (int(adv["End_Timestamp"]) - int(adv["Start_Timestamp"])) / 1e3
@@ -78,12 +82,14 @@ def digest(trace_dir, out_dir):
         gap = 0.0 if prev_end is None else (int(adv["Start_Timestamp"]) - prev_end) / 1e3
         gap2 = (int(dec["Start_Timestamp"]) - int(adv["End_Timestamp"])) / 1e3
         prev_end = int(dec["End_Timestamp"])
+        n0, b = grp[0]
         active = int((used > n0).sum())
-        samples = active * b
+        samples = sum(int((used > m0).sum()) * bb for m0, bb in grp)
         tot_adv += a_us
         tot_dec += d_us
         tot_gap += gap + gap2
-        print(f"| {i} | {n0} | {b} | {active} | {a_us:.1f} | {d_us:.1f} | {gap + gap2:.1f} | {samples} | {samples / a_us / 1e3 if a_us > 0 else 0:.1f} |")
+        label = f"{i if not burst else (0 if i == 0 else burst + i - 1)}" if len(grp) == 1 else f"0-{len(grp) - 1} (one launch)"
+        print(f"| {label} | {n0} | {b} | {active} | {a_us:.1f} | {d_us:.1f} | {gap + gap2:.1f} | {samples} | {samples / a_us / 1e3 if a_us > 0 else 0:.1f} |")
     span = (prev_end - t_first) / 1e3
     print()
     print(f"first advance start .. last decide end: {span:.1f} us; advance kernels {tot_adv:.1f} us ({100 * tot_adv / span:.1f} %), "
