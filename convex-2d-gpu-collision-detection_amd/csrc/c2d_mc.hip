@@ -409,6 +409,7 @@ __global__ void mc_scenes_init_kernel(AdaptiveState* state, uint32_t n_scenes)
 // 6 waves per SIMD (80 VGPRs, two dwords spilled) instead of the 5 the compiler's 81 VGPRs allow: the certain-miss path is a
 // chain of dependent Philox multiplies, and the sixth wave is worth 5 % on the config-4 workload (806.7 -> 765.5 ms per
 // 4e6 data points) and 4 % on the reference-default batch; 8 waves (64 VGPRs, 17 dwords spilled) give nothing more.
+template <bool BURST>
 __global__ __launch_bounds__(kMcBlock, 6) void mc_scenes_advance_kernel(ScenesArgs A)
 {
     __shared__ WaveQueue s_queue[kWavesPerBlock];
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(kMcBlock, 6) void mc_scenes_advance_kernel(ScenesAr
     wps = (n_batch + chunk - 1) / chunk;
 
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (A.burst_steps > 1) {  // first launch of a call: n_start == 0, identity list, one work item per scene
+    if constexpr (BURST) {  // first launch of a call: n_start == 0, identity list, one work item per scene
         for (uint64_t item = (uint64_t)blockIdx.x * kWavesPerBlock + wave; item < n_active; item += (uint64_t)gridDim.x * kWavesPerBlock) {
             const uint32_t g = (uint32_t)item;
             const PositionWithVarAndPoseIdx row = A.scenes[g];
@@ -825,12 +826,12 @@ int c2d_mc_scenes(c2d_ctx* ctx, const c2d_mc_scenes_args* a, c2d_stream stream)
         ScenesArgs AB = A;
         DecideArgs DB = D;
         AB.burst_steps = DB.burst_steps = burst;
-        hipLaunchKernelGGL(mc_scenes_advance_kernel, dim3((unsigned)adv_blocks), dim3(kMcBlock), 0, s, AB);
+        hipLaunchKernelGGL(mc_scenes_advance_kernel<true>, dim3((unsigned)adv_blocks), dim3(kMcBlock), 0, s, AB);
         hipLaunchKernelGGL(mc_scenes_decide_kernel, dim3((unsigned)dec_blocks), dim3(256), 0, s, DB);
         it = burst;
     }
     for (; it < steps; it++) {
-        hipLaunchKernelGGL(mc_scenes_advance_kernel, dim3((unsigned)adv_blocks), dim3(kMcBlock), 0, s, A);
+        hipLaunchKernelGGL(mc_scenes_advance_kernel<false>, dim3((unsigned)adv_blocks), dim3(kMcBlock), 0, s, A);
         hipLaunchKernelGGL(mc_scenes_decide_kernel, dim3((unsigned)dec_blocks), dim3(256), 0, s, D);
     }
     C2D_LAUNCH_CHECK(ctx);
