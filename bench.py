@@ -562,7 +562,7 @@ def main() -> None:
         sgbs = 67 * npoly / (sms * 1e-3) / 1e9
         poly_leg["small_polygons"] = {"metric": "poly_pair_tests_per_s (K ~ U{3..4}, 4-row layout, per GPU)", "value": npoly / (sms * 1e-3),
                                       "kernel_ms": round(sms, 5), "collide_rate": float(pout.to(torch.int64).sum().item()) / npoly,
-                                      "roofline": {"bound": "hbm", "kernel": "sat_poly_kernel<4, 8, false>", "achieved": round(sgbs, 1),
+                                      "roofline": {"bound": "hbm", "kernel": "sat_poly4_kernel", "achieved": round(sgbs, 1),
                                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(sgbs / HBM_PEAK_GBS, 4),
                                                    "algorithmic_bytes_per_launch": 67 * npoly, "traffic": None}}
         del vx4, vy4, kk4, pout

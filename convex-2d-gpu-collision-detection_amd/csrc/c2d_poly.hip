@@ -254,6 +254,68 @@ __global__ __launch_bounds__(64, MIN_WAVES) void sat_poly_kernel(const float* __
     if (d_count) wave_count_arrive_total(n_collide, d_count, words);
 }
 
+// ---- triangles and quadrilaterals in a 4-row layout: the rectangle kernel's shape ---------------------------------
+// With at most 4 + 4 vertices the full evaluation — 8 true-normal axes x 8 vertices — costs what the rectangle SAT
+// costs, so there is nothing to gain from a cheap first axis: a lane takes 4 consecutive pairs with 16-byte loads (16
+// loads in flight, as sat_rect_verts_kernel), pads each polygon by repeating vertex 0 (exactly neutral, see above) and
+// evaluates everything in registers.  No LDS, no second phase: dense and sparse scenes run at the same, HBM-bound rate.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(64) void sat_poly4_kernel(const float* __restrict__ vx, const float* __restrict__ vy,
+                                                       const uint8_t* __restrict__ kcnt, size_t n, size_t n_groups,
+                                                       uint8_t* __restrict__ out, unsigned long long* __restrict__ d_count,
+                                                       unsigned long long* __restrict__ words, uint32_t* __restrict__ async_err)
+{
+    uint32_t my_count = 0;
+    bool any_bad = false;
+    const size_t stride = (size_t)gridDim.x * 64;
+    for (size_t g = (size_t)blockIdx.x * 64 + threadIdx.x; g < n_groups; g += stride) {
+        f32x4 X[8], Y[8];  // rows 0..3 = polygon A, 4..7 = polygon B; element e = pair 4 g + e
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            X[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vx + (size_t)r * n) + g);
+            Y[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vy + (size_t)r * n) + g);
+        }
+        const uint32_t kA4 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(kcnt) + g);
+        const uint32_t kB4 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(kcnt + n) + g);
+        uint32_t packed = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            int ka = (int)((kA4 >> (8 * e)) & 0xffu), kb = (int)((kB4 >> (8 * e)) & 0xffu);
+            const bool bad = ka < 1 || ka > 4 || kb < 1 || kb > 4;
+            any_bad |= bad;
+            ka = ka < 1 ? 1 : (ka > 4 ? 4 : ka);
+            kb = kb < 1 ? 1 : (kb > 4 ? 4 : kb);
+            float px[8], py[8];  // A's 4 slots then B's 4 slots
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                px[r] = r < ka ? X[r][e] : X[0][e];
+                py[r] = r < ka ? Y[r][e] : Y[0][e];
+                px[4 + r] = r < kb ? X[4 + r][e] : X[4][e];
+                py[4 + r] = r < kb ? Y[4 + r][e] : Y[4][e];
+            }
+            bool sep = false;
+#pragma unroll
+            for (int a = 0; a < 8; a++) {
+                const int i0 = a, i1 = (a & 4) | ((a + 1) & 3);
+                const float nx = -(py[i1] - py[i0]), ny = px[i1] - px[i0];
+                float mn1 = __builtin_inff(), mx1 = -__builtin_inff(), mn2 = __builtin_inff(), mx2 = -__builtin_inff();
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    minmax_update(nx, ny, px[r], py[r], mn1, mx1);
+                    minmax_update(nx, ny, px[4 + r], py[4 + r], mn2, mx2);
+                }
+                sep |= (mx1 < mn2) || (mx2 < mn1);
+            }
+            packed |= ((sep || bad) ? 0u : 1u) << (8 * e);
+        }
+        my_count += (uint32_t)__popc(packed);
+        __builtin_nontemporal_store(packed, reinterpret_cast<uint32_t*>(out) + g);
+    }
+    if (__ballot(any_bad) != 0 && threadIdx.x == 0) __hip_atomic_fetch_or(async_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (d_count) wave_count_arrive(my_count, d_count, words);
+}
+
 template <int KM, int MIN_WAVES, bool FULL>
 static void launch_poly(hipStream_t s, const float* d_vx, const float* d_vy, const uint8_t* d_k, size_t n, int rows, uint8_t* d_out,
                         unsigned long long* d_count, unsigned long long* words, uint32_t* async_err)
@@ -281,7 +343,13 @@ int c2d_sat_poly_pairs_rows(c2d_ctx* ctx, const float* d_vx, const float* d_vy, 
     if (int rc = workspace_acquire(ctx, s, d_count != nullptr)) return rc;
     uint32_t* err = ctx->d_async_err;
     unsigned long long* words = ctx->d_count_words;
-    if (rows == 16) launch_poly<16, 5, true>(s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words, err);
+    auto aligned = [](const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
+    if (rows == 4 && n % 4 == 0 && aligned(d_vx, 16) && aligned(d_vy, 16) && aligned(d_k, 4) && aligned(d_out, 4)) {
+        const size_t n_groups = n / 4;
+        const size_t blocks = (n_groups + 63) / 64;
+        hipLaunchKernelGGL(sat_poly4_kernel, dim3((unsigned)(blocks < (size_t)kMaxGrid ? blocks : (size_t)kMaxGrid)), dim3(64), 0, s, d_vx, d_vy, d_k, n,
+                           n_groups, d_out, d_count, words, err);
+    } else if (rows == 16) launch_poly<16, 5, true>(s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words, err);
     else if (rows > 8) launch_poly<16, 5, false>(s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words, err);
     else if (rows > 4) launch_poly<8, 7, false>(s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words, err);
     else launch_poly<4, 8, false>(s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words, err);

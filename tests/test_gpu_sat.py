@@ -273,12 +273,14 @@ def test_poly_dense_scenes(eng, oracle, wl, n, kmin, kmax, extent):
     assert 0.2 < ref.mean() < 1.0
 
 
-@pytest.mark.parametrize("rows,kmin,kmax,n,extent", [(4, 3, 4, 100_003, 8.0), (4, 1, 4, 30_001, 0.6), (3, 3, 3, 5000, 1.0), (8, 3, 8, 100_003, 8.0),
+@pytest.mark.parametrize("rows,kmin,kmax,n,extent", [(4, 3, 4, 100_000, 8.0), (4, 1, 4, 40_000, 0.6), (4, 3, 4, 4, 1.0), (4, 2, 4, 260, 0.8), (4, 3, 3, 1_000_000, 2.0),
+                                                     (4, 3, 4, 100_003, 8.0), (4, 1, 4, 30_001, 0.6), (3, 3, 3, 5000, 1.0), (8, 3, 8, 100_003, 8.0),
                                                      (8, 5, 8, 30_001, 0.8), (6, 3, 6, 20_000, 1.5), (12, 3, 12, 50_001, 2.0), (9, 9, 9, 777, 1.0),
                                                      (16, 3, 16, 10_000, 1.0), (1, 1, 1, 200, 1.0)])
 def test_poly_row_layouts(eng, pkg, oracle, wl, rows, kmin, kmax, n, extent):
     """c2d_sat_poly_pairs_rows: layouts with fewer than C2D_POLY_KMAX vertex rows per polygon run the kernel instances sized
-    for 4 / 8 / 16 slots (rows <= 4: eight pairs per wave in the full evaluation, rows <= 8: four); sparse and dense scenes."""
+    for 4 / 8 / 16 slots (rows <= 4: eight pairs per wave in the full evaluation, rows <= 8: four); sparse and dense scenes.
+    rows == 4 with n a multiple of 4 takes the register-only kernel (4 pairs per lane, all 8 axes, no second phase)."""
     vx, vy, k = wl.random_convex_polygons(n, seed=rows * 1000 + n, kmin=kmin, kmax=kmax, extent=extent, rows=rows)
     ref, ref_cnt = oracle.sat_poly_pairs(vx, vy, k)
     dvx, dvy, dk = eng.to_device(vx), eng.to_device(vy), eng.to_device(k)
