@@ -565,6 +565,10 @@ def main() -> None:
                                       "roofline": {"bound": "hbm", "kernel": "sat_poly4_kernel", "achieved": round(sgbs, 1),
                                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(sgbs / HBM_PEAK_GBS, 4),
                                                    "algorithmic_bytes_per_launch": 67 * npoly, "traffic": None}}
+        c4 = counts.get("sat_poly4.small_polygons", {})
+        if c4.get("pairs") == npoly and c4.get("hbm_bytes_per_launch"):
+            poly_leg["small_polygons"]["roofline"]["traffic"] = c4["hbm_bytes_per_launch"]
+            poly_leg["small_polygons"]["roofline"]["traffic_source"] = "recorded, not measured in this run: %s" % c4.get("source")
         del vx4, vy4, kk4, pout
 
     # ---- CPU baseline: oracle port on this host, rank 0, N = 1 only ------------------------------
