@@ -140,13 +140,35 @@ C2D_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uin
     return U4{c0, c1, c2, c3};
 }
 
-// block j (0 or 1) of sample `sample` in stream (seed, scene)
+// block j (0 or 1) of item `sample` in stream (seed, scene): the scene sampler's layout (sample_scenes_kernel)
 C2D_DEV U4 philox_block(uint64_t seed, uint64_t scene, uint64_t sample, uint32_t j)
 {
     uint64_t blk = 2 * sample + j;
     return philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)scene, (uint32_t)(scene >> 32),
                          (uint32_t)seed, (uint32_t)(seed >> 32));
 }
+
+// ---- draw layout of the Monte-Carlo loop --------------------------------------------------------------------
+// The samples of a stream (seed, scene) are drawn in GROUPS OF FOUR: sample s belongs to group g = s >> 2 as member
+// j = s & 3, and the group owns Philox blocks 8g .. 8g+5 of subsequence `scene` (rocRAND: offset = 4 * (8g + b)):
+//   block 8g+0   word j          radius word of sample j's first Box-Muller pair  (-> dx, dy)
+//   block 8g+1   word j          angle word of that pair
+//   block 8g+2   words (x,y)     radius, angle word of sample 0's second pair     (-> dtheta, dw);  (z,w): sample 1's
+//   block 8g+3   words (x,y)     ... sample 2's;  (z,w): sample 3's
+//   block 8g+4,5 like 8g+2,3     third pair (-> dh, second normal unused); only evaluated when sigma_h != 0
+// Why: the radius word alone proves most samples of a far scene to be certain misses (c2d_mc.hip, make_scene), and a
+// Philox block costs ~65 instructions whatever is used of it.  With one block per sample that proof cost a block per
+// sample; with the four radius words of a group in ONE block it costs a quarter.  A near scene still pays one block per
+// sample (four blocks per group), a shape-variance scene 1.5 instead of 2.
+C2D_DEV U4 philox_draw_block(uint64_t seed, uint64_t scene, uint64_t group, uint32_t b)
+{
+    uint64_t blk = 8 * group + b;
+    return philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)scene, (uint32_t)(scene >> 32),
+                         (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+// word j (0..3) of a block; j is a compile-time constant wherever this is used in a hot loop
+C2D_DEV uint32_t u4_word(const U4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
 
 // Box-Muller: x -> radius, y -> angle; n0 uses sin, n1 cos (rocRAND's roles)
 C2D_DEV void box_muller(uint32_t x, uint32_t y, float& n0, float& n1)

@@ -9,16 +9,16 @@
 // Mapping.  The reference gives one thread one scene and runs its samples
 // serially.  Here one *wave* (64 lanes) owns one (scene, sample
 // chunk): the scene constants are wave-uniform (scalar registers), lane l
-// evaluates samples chunk_begin + l, + 64, ..., and hits are counted with
-// ballot + popcount in a scalar register.  The random stream is counter based
-// (Philox4x32-10 keyed by seed, scene, sample), so there is no RNG state in
+// evaluates the four samples of group chunk_begin / 4 + l, + 64, ..., and hits are
+// counted with ballot + popcount in a scalar register.  The random stream is counter based
+// (Philox4x32-10 keyed by seed, scene, sample group: c2d_math.hpp), so there is no RNG state in
 // memory, no set-up kernel, and any partition of the samples over waves, blocks
 // or GPUs gives the same hit count.  The kernel is VALU bound (~0 B of HBM
 // traffic per sample); see DESIGN.md for the per-sample op budget.
 //
 // Work avoidance that cannot change a result: a sample whose obstacle centre alone
 // proves a miss (bounding-disk argument, make_scene) is dropped after its first
-// Box-Muller pair, or — from the raw radius word — before any transcendental; the
+// Box-Muller pair, or — from the raw radius word, four samples per Philox block — before any transcendental; the
 // undecided samples of a wave are compacted through an LDS queue so that the full
 // evaluation always runs on 64 busy lanes.
 #include "c2d_internal.hpp"
@@ -131,30 +131,31 @@ C2D_DEV bool centre_pretest(const Scene& sc, float dx, float dy)
     return (t0 > sc.phi[0]) | (t0 < sc.plo[0]) | (t1 > sc.phi[1]) | (t1 < sc.plo[1]);
 }
 
-// The sampled obstacle of one sample (reference utils.cu:144-157), in two steps: the first
-// Philox block and its first Box-Muller pair give the centre (dx, dy); the rest (dtheta, dw,
-// dh, rotation, vertices) is only needed when the centre pretest cannot rule the sample out.
-// The second Philox block only feeds dh; it is skipped when sigma_h == 0 because dh = n*0
-// cannot change any vertex (the product is +-0 and is only ever added).
-C2D_DEV void sample_centre(const Scene& sc, const U4& a, float& dx, float& dy)
+// The sampled obstacle of one sample (reference utils.cu:144-157), in two steps: the first Box-Muller pair gives the
+// centre (dx, dy); the rest (dtheta, dw, dh, rotation, vertices) is only needed when the centre pretest cannot rule the
+// sample out.  The words come from the sample's group (draw layout: c2d_math.hpp, philox_draw_block).  The third pair
+// only feeds dh; its block is skipped when sigma_h == 0 because dh = n*0 cannot change any vertex (the product is +-0
+// and is only ever added).
+C2D_DEV void sample_centre(const Scene& sc, uint32_t radius_word, uint32_t angle_word, float& dx, float& dy)
 {
     float n0, n1;
-    box_muller(a.x, a.y, n0, n1);
+    box_muller(radius_word, angle_word, n0, n1);
     dx = n0 * sc.sx;
     dy = n1 * sc.sy;
 }
 
-C2D_DEV void sample_obstacle(const Scene& sc, uint32_t az, uint32_t aw, float dx, float dy, uint64_t seed,
+C2D_DEV void sample_obstacle(const Scene& sc, uint32_t radius_word, uint32_t angle_word, float dx, float dy, uint64_t seed,
                              uint64_t scene_id, uint64_t sample, float (&o)[8])
 {
     float n2, n3;
-    box_muller(az, aw, n2, n3);
+    box_muller(radius_word, angle_word, n2, n3);
     const float dt = n2 * sc.st, dw = n3 * sc.sw;
     float dh = 0.0f;
     if (sc.sh != 0.0f) {  // wave-uniform
-        const U4 b = philox_block(seed, scene_id, sample, 1);
+        const U4 b = philox_draw_block(seed, scene_id, sample >> 2, 4u + ((uint32_t)(sample >> 1) & 1u));
+        const bool odd = (sample & 1) != 0;
         float n4, unused;
-        box_muller(b.x, b.y, n4, unused);
+        box_muller(odd ? b.z : b.x, odd ? b.w : b.y, n4, unused);
         dh = n4 * sc.sh;
     }
     // r_out = r_in + create_rect(dw, dh): half extents add (utils.cu:152-155)
@@ -199,103 +200,289 @@ C2D_DEV bool sample_collides(const Scene& sc, const float (&o)[8])
 #ifndef C2D_MC_ILP
 #define C2D_MC_ILP 2
 #endif
-[[maybe_unused]] constexpr int kIlp = C2D_MC_ILP;  // Philox blocks computed side by side on the far-scene path
-constexpr int kQueueSlots = 128;  // per wave: < 64 left over + at most 64 pushed per iteration
+#ifndef C2D_MC_FAR_X0
+#define C2D_MC_FAR_X0 0x40000000u  // a quarter of the radius words are candidates
+#endif
+[[maybe_unused]] constexpr uint32_t kFarX0 = C2D_MC_FAR_X0;
+[[maybe_unused]] constexpr int kIlp = C2D_MC_ILP;  // radius blocks computed side by side on the far-scene path
+constexpr int kQueueSlots = 128;      // < 64 left over + at most 64 pushed per step
+constexpr int kCandSlots = 64 + 256 * C2D_MC_ILP;  // < 64 left over + every sample of the iterations fetched together
 
-// Per-wave queue of samples the centre pretest could not rule out.  A far or mid-range scene
-// rules out most samples of an iteration but rarely all 64, and a SIMD wave pays for the full
-// evaluation as soon as one lane needs it; so undecided samples are parked here (centre, the two
-// unused Philox words, sample offset) and evaluated 64 at a time, all lanes busy.
+// Per-wave LDS.  Two ways to run a scene, chosen per scene (wave-uniform):
+//  * NEAR (the radius word proves little or nothing): a lane owns a group of four samples and shares the group's Philox
+//    blocks among them; samples the centre pretest cannot rule out are parked in `cw/idx` and evaluated 64 at a time.
+//  * FAR (the radius word alone proves at least three samples in four to be misses): the four radius words of a group
+//    cost one Philox block, and everything after that works on COMPACTED samples, 64 busy lanes at a time:
+//    candidates (radius word, offset) wait in `cand` for their angle word / Box-Muller / centre pretest, the undecided
+//    ones among them in `und` for the full evaluation.  Each of these later stages draws the block it needs per sample.
 struct WaveQueue {
-    float4 cw[kQueueSlots];      // dx, dy, bits(a.z), bits(a.w)
-    uint32_t idx[kQueueSlots];   // sample offset within the chunk
+    union {
+        struct {
+            float4 cw[kQueueSlots];      // dx, dy, bits(radius word 2), bits(angle word 2)
+            uint32_t idx[kQueueSlots];   // sample offset within the chunk
+            // Lane-private stash of the open iteration's Philox blocks, word-major so that lane l reads word w at [w][l]
+            // without bank conflicts: the words are consumed one sub-iteration at a time, across the full evaluation of 64
+            // samples, and 16 registers of state held over that evaluation cost the kernel its sixth wave per SIMD
+            uint32_t r[4][64];           // radius block (block 0 of the groups)
+            uint32_t a[4][64];           // angle block (block 1)
+            uint32_t p[4][64];           // block 2 / 3: second Box-Muller pairs of members 0,1 / 2,3
+        } near;
+        struct {
+            uint2 cand[kCandSlots];      // radius word, sample offset within the chunk
+            float2 und_c[kQueueSlots];   // dx, dy
+            uint32_t und_idx[kQueueSlots];
+        } far;
+    };
 };
+
+// ---- NEAR: hits among samples [begin, begin + count) of one scene, computed by one wave.  A lane owns one GROUP of four
+// samples per iteration (draw layout: c2d_math.hpp), so an iteration covers 256 consecutive samples; sub-iteration
+// j = 0..3 handles member j of the 64 groups.  begin and count are arbitrary (a shard may start inside a group):
+// positions outside [begin, begin + count) are masked, never drawn into the result.
+//
+// The body is one loop around a small state machine — open an iteration / produce a sub-iteration / evaluate 64 samples —
+// so that each expensive piece (Box-Muller of the centre, the full evaluation) exists ONCE in the kernel's code: unrolled
+// over j the kernel was 90 KB, more than the instruction cache holds, and ran 30 % slower than the one-sample-per-lane
+// kernel it replaced.
+C2D_DEV uint32_t wave_count_hits_near(const Scene& sc, uint64_t seed, uint64_t scene_id, uint64_t begin, uint32_t count,
+                                      WaveQueue& wq)
+{
+    auto& q = wq.near;
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t hits = 0;    // wave-uniform (scalar) accumulator
+    uint32_t qn = 0;      // queued samples (wave-uniform)
+    uint32_t dense = 0;   // sub-iterations to evaluate in place after the pretest ruled nothing out
+    // (count < 2^31 — the callers cut work into far smaller chunks — keeps every offset below in 32 bits)
+    const uint64_t g0 = begin >> 2;                        // first group touched
+    const uint32_t base = (uint32_t)(begin & 3);           // position of sample `begin` inside it
+    const uint32_t end_pos = base + count;                 // this call's samples are positions [base, end_pos) from 4 * g0
+    const uint32_t n_groups = (end_pos + 3) >> 2;
+
+    uint32_t gi = 0;      // next group offset to open
+    // the iteration being produced (all wave-uniform)
+    uint32_t cgi = 0;     // its group offset
+    bool have = false;    // q.p holds block 2 (j < 2) / 3 (j >= 2) of the lanes' groups
+    uint32_t j = 4;       // next sub-iteration; 4: no iteration open
+    uint32_t lo = 0, hi = 0;
+    auto stash = [&](uint32_t (&dst)[4][64], const U4& v) { dst[0][lane] = v.x; dst[1][lane] = v.y; dst[2][lane] = v.z; dst[3][lane] = v.w; };
+
+    for (;;) {
+        bool direct = false;  // evaluate this sub-iteration's samples straight from the registers
+        float dx = 0.0f, dy = 0.0f;
+        uint32_t w2r = 0, w2a = 0, sidx = 0;
+        bool live = false;
+        if (j < 4) {
+            // ---- produce sub-iteration j: member j of the 64 groups
+            if (j == 2) have = false;
+            const uint32_t pos = 4 * lane + j;
+            const bool in_range = pos >= lo && pos < hi;
+            const uint32_t rw = q.r[j][lane];
+            const uint32_t odd2 = 2 * (j & 1);
+            const uint32_t half = j >> 1;
+            sidx = 4 * cgi - base + pos;   // chunk offset (wraps only where masked)
+            j++;
+            bool undecided = in_range;
+            if (dense) {  // every lane needs the full evaluation anyway
+                dense--;
+                sample_centre(sc, rw, q.a[j - 1][lane], dx, dy);
+                live = in_range;
+                direct = true;
+            } else {
+#ifndef C2D_MC_NO_PRETEST
+                undecided = in_range && !(sc.use_x0 && rw >= sc.x0);   // the radius word alone may prove the miss
+                if (__ballot(undecided) == 0ull) continue;
+#endif
+                sample_centre(sc, rw, q.a[j - 1][lane], dx, dy);
+#ifndef C2D_MC_NO_PRETEST
+                undecided = undecided && !centre_pretest(sc, dx, dy);
+#endif
+            }
+            const unsigned long long m = __ballot(undecided);
+            if (!direct) {
+                if (m == 0ull) continue;  // 64 certain misses
+                if (m == ~0ull) dense = C2D_MC_PRETEST_HOLDOFF;
+            }
+            if (!have) { stash(q.p, philox_draw_block(seed, scene_id, g0 + cgi + lane, 2 + half)); have = true; }
+            w2r = q.p[odd2][lane];
+            w2a = q.p[odd2 + 1][lane];
+            if (!direct) {
+                if (undecided) {
+                    const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    q.cw[slot] = make_float4(dx, dy, __uint_as_float(w2r), __uint_as_float(w2a));
+                    q.idx[slot] = sidx;
+                }
+                qn += (uint32_t)__popcll(m);
+                if (qn < 64) continue;
+            }
+        } else if (gi < n_groups) {
+            // ---- open the next iteration: radius and angle blocks of its 64 groups
+            cgi = gi;
+            gi += 64;
+            const uint32_t p0 = 4 * cgi;                                  // position of the iteration's first sample
+            lo = p0 >= base ? 0u : base;                                   // (p0 < base only for the first iteration)
+            const uint32_t rem = end_pos - p0;
+            hi = rem < 256 ? rem : 256u;
+            stash(q.r, philox_draw_block(seed, scene_id, g0 + cgi + lane, 0));
+            stash(q.a, philox_draw_block(seed, scene_id, g0 + cgi + lane, 1));
+            have = false;
+            j = 0;
+            continue;
+        } else if (qn == 0) {
+            break;
+        }
+        // ---- evaluate 64 samples: this sub-iteration's (direct) or queued ones (a full wave of them, or what is left
+        // at the end).  Lanes read slots that other lanes of this wave wrote: LDS operations of a wave complete in
+        // order, the fence pairs only stop the compiler from reordering the reads above the writes and later writes
+        // above the reads (no instruction is emitted)
+        if (!direct) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t take = qn < 64 ? qn : 64;
+            live = lane < take;
+            const uint32_t src = qn - take + (live ? lane : 0);
+            const float4 e = q.cw[src];
+            sidx = q.idx[src];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            qn -= take;
+            dx = e.x;
+            dy = e.y;
+            w2r = __float_as_uint(e.z);
+            w2a = __float_as_uint(e.w);
+        }
+        float o[8];
+        sample_obstacle(sc, w2r, w2a, dx, dy, seed, scene_id, begin + sidx, o);
+        hits += (uint32_t)__popcll(__ballot(sample_collides(sc, o) && live));
+    }
+    return hits;
+}
+
+#ifndef C2D_MC_NO_PRETEST
+// ---- FAR: the same count for a scene whose radius test (make_scene: raw word >= x0 proves the miss) passes at most one
+// sample in four.  Three stages, each on 64 busy lanes, each present once in the code:
+//   1  radius blocks: one Philox block per group of four samples, kIlp iterations (256 samples each) side by side —
+//      independent multiply chains per lane — until 64 candidates wait or the input ends; an iteration without a
+//      candidate costs nothing beyond its block;
+//   2  64 candidates: angle word (block 1 of the candidate's group), Box-Muller, centre pretest; the undecided ones queue;
+//   3  64 undecided samples: second pair's block (2 / 3 of the group), full evaluation.
+C2D_DEV uint32_t wave_count_hits_far(const Scene& sc, uint64_t seed, uint64_t scene_id, uint64_t begin, uint32_t count,
+                                     WaveQueue& wq)
+{
+    auto& q = wq.far;
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t hits = 0, cn = 0, un = 0;  // wave-uniform: hits, queued candidates, queued undecided samples
+    const uint64_t g0 = begin >> 2;
+    const uint32_t base = (uint32_t)(begin & 3);
+    const uint32_t end_pos = base + count;
+    const uint32_t n_groups = (end_pos + 3) >> 2;
+    const uint32_t x0 = sc.x0;
+    uint32_t gi = 0;
+
+    // one lane-private word of an iteration: queue it if it is a candidate
+    auto push_word = [&](uint32_t word, bool in_range, uint32_t sidx) {
+        const bool c = in_range && word < x0;
+        const unsigned long long m = __ballot(c);
+        if (m == 0ull) return;
+        if (c) {
+            const uint32_t slot = cn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            q.cand[slot] = make_uint2(word, sidx);
+        }
+        cn += (uint32_t)__popcll(m);
+    };
+    auto push_block = [&](const U4& r, uint32_t cgi) {
+        if (__ballot((r.x < x0) | (r.y < x0) | (r.z < x0) | (r.w < x0)) == 0ull) return;  // 256 certain misses
+        const uint32_t p0 = 4 * cgi;
+        const uint32_t lo = p0 >= base ? 0u : base;
+        const uint32_t rem = end_pos - p0;
+        const uint32_t hi = rem < 256 ? rem : 256u;
+        const uint32_t pos = 4 * lane;
+        const uint32_t sidx = p0 - base + pos;
+        push_word(r.x, pos + 0 >= lo && pos + 0 < hi, sidx + 0);
+        push_word(r.y, pos + 1 >= lo && pos + 1 < hi, sidx + 1);
+        push_word(r.z, pos + 2 >= lo && pos + 2 < hi, sidx + 2);
+        push_word(r.w, pos + 3 >= lo && pos + 3 < hi, sidx + 3);
+    };
+
+    for (;;) {
+        // ---- stage 1
+        while (cn < 64 && gi + 64 * kIlp <= n_groups) {
+            U4 rr[kIlp];
+#pragma unroll
+            for (int k = 0; k < kIlp; k++) rr[k] = philox_draw_block(seed, scene_id, g0 + gi + 64 * k + lane, 0);
+#pragma unroll
+            for (int k = 0; k < kIlp; k++) push_block(rr[k], gi + 64 * k);
+            gi += 64 * kIlp;
+        }
+        while (cn < 64 && gi < n_groups) {  // the last, partial look-ahead
+            push_block(philox_draw_block(seed, scene_id, g0 + gi + lane, 0), gi);
+            gi += 64;
+        }
+        const bool drained = gi >= n_groups;
+        // ---- stage 2: up to 64 candidates (fewer only when the input has ended).  Lanes read slots other lanes of this
+        // wave wrote; the fences only constrain the compiler (see wave_count_hits_near)
+        if (cn) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t take = cn < 64 ? cn : 64;
+            const bool live = lane < take;
+            const uint2 e = q.cand[cn - take + (live ? lane : 0)];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            cn -= take;
+            const uint64_t s = begin + e.y;
+            const U4 a = philox_draw_block(seed, scene_id, s >> 2, 1);
+            const uint32_t jj = (uint32_t)s & 3u;
+            const uint32_t aw = jj == 0 ? a.x : (jj == 1 ? a.y : (jj == 2 ? a.z : a.w));
+            float dx, dy;
+            sample_centre(sc, e.x, aw, dx, dy);
+            const bool undecided = live && !centre_pretest(sc, dx, dy);
+            const unsigned long long m = __ballot(undecided);
+            if (undecided) {
+                const uint32_t slot = un + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                q.und_c[slot] = make_float2(dx, dy);
+                q.und_idx[slot] = e.y;
+            }
+            un += (uint32_t)__popcll(m);
+        }
+        // ---- stage 3: 64 undecided samples, or what is left once nothing more can come
+        if (un >= 64 || (drained && cn == 0 && un)) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t take = un < 64 ? un : 64;
+            const bool live = lane < take;
+            const uint32_t src = un - take + (live ? lane : 0);
+            const float2 c = q.und_c[src];
+            const uint32_t sidx = q.und_idx[src];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            un -= take;
+            const uint64_t s = begin + sidx;
+            const U4 pb = philox_draw_block(seed, scene_id, s >> 2, 2u + ((uint32_t)(s >> 1) & 1u));
+            const bool odd = (s & 1) != 0;
+            float o[8];
+            sample_obstacle(sc, odd ? pb.z : pb.x, odd ? pb.w : pb.y, c.x, c.y, seed, scene_id, s, o);
+            hits += (uint32_t)__popcll(__ballot(sample_collides(sc, o) && live));
+        }
+        if (drained && cn == 0 && un == 0) break;
+    }
+    return hits;
+}
+#endif
 
 // hits among samples [begin, begin + count) of one scene, computed by one wave
 C2D_DEV uint32_t wave_count_hits(const Scene& sc, uint64_t seed, uint64_t scene_id, uint64_t begin, uint32_t count,
                                  WaveQueue& q)
 {
-    const uint32_t lane = threadIdx.x & 63;
-    uint32_t hits = 0;    // wave-uniform (scalar) accumulator
-    uint32_t qn = 0;      // queued samples (wave-uniform)
-    uint32_t dense = 0;   // iterations to evaluate in place after the pretest ruled nothing out
-
-    // evaluate 64 queued samples (the last qn on the flush trip).  Lanes read slots that other lanes of this wave
-    // wrote: LDS operations of a wave complete in order, the fence pairs only stop the compiler from reordering the
-    // reads above the writes and later writes above the reads (no instruction is emitted)
-    auto drain64 = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const uint32_t take = qn < 64 ? qn : 64;
-        const bool live = lane < take;
-        const uint32_t src = qn - take + (live ? lane : 0);
-        const float4 e = q.cw[src];
-        const uint32_t eidx = q.idx[src];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        qn -= take;
-        float o[8];
-        sample_obstacle(sc, __float_as_uint(e.z), __float_as_uint(e.w), e.x, e.y, seed, scene_id, begin + eidx, o);
-        hits += (uint32_t)__popcll(__ballot(sample_collides(sc, o) && live));
-    };
-    // one iteration's 64 samples, given their first Philox block, from the obstacle centre on
-    auto process = [&](uint32_t idx, bool in_range, const U4& a) {
-        float dx, dy;
-        sample_centre(sc, a, dx, dy);
-        if (dense) {  // near scene: every lane needs the full evaluation anyway
-            dense--;
-            float o[8];
-            sample_obstacle(sc, a.z, a.w, dx, dy, seed, scene_id, begin + idx, o);
-            hits += (uint32_t)__popcll(__ballot(sample_collides(sc, o) && in_range));
-            return;
-        }
-#ifdef C2D_MC_NO_PRETEST
-        const bool undecided = in_range;
-#else
-        const bool undecided = in_range && !centre_pretest(sc, dx, dy);
-#endif
-        const unsigned long long m = __ballot(undecided);
-        if (m == 0ull) return;  // the common case of a far scene: 64 certain misses
-        if (m == ~0ull) dense = C2D_MC_PRETEST_HOLDOFF;
-        if (undecided) {
-            const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            q.cw[pos] = make_float4(dx, dy, __uint_as_float(a.z), __uint_as_float(a.w));
-            q.idx[pos] = idx;
-        }
-        qn += (uint32_t)__popcll(m);
-        if (qn >= 64) drain64();
-    };
-
-    uint32_t off = 0;
-    while (off < count) {
 #ifndef C2D_MC_NO_PRETEST  // validation builds evaluate every sample in full
-        // Far scene (the radius word alone can prove a miss): kIlp iterations' Philox blocks are computed side by side —
-        // independent multiply chains per lane instead of one — and an iteration whose 64 radius words all prove
-        // a miss costs nothing beyond them.
-        if (sc.use_x0 && dense == 0 && off + 64 * kIlp <= count) {
-            U4 a[kIlp];
-#pragma unroll
-            for (int b = 0; b < kIlp; b++) a[b] = philox_block(seed, scene_id, begin + off + 64 * b + lane, 0);
-#pragma unroll
-            for (int b = 0; b < kIlp; b++)
-                if (__ballot(a[b].x < sc.x0) != 0ull) process(off + 64 * b + lane, true, a[b]);
-            off += 64 * kIlp;
-            continue;
-        }
+    if (sc.use_x0 && sc.x0 < kFarX0) return wave_count_hits_far(sc, seed, scene_id, begin, count, q);
 #endif
-        const uint32_t idx = off + lane;
-        const bool in_range = idx < count;
-        const U4 a = philox_block(seed, scene_id, begin + idx, 0);
-        off += 64;
-#ifndef C2D_MC_NO_PRETEST
-        if (sc.use_x0 && dense == 0 && __ballot(in_range && a.x < sc.x0) == 0ull) continue;
-#endif
-        process(idx, in_range, a);
-    }
-    while (qn) drain64();  // what is left in the queue
-    return hits;
+    return wave_count_hits_near(sc, seed, scene_id, begin, count, q);
 }
 
 // ---- one scene, sample-parallel (BASELINE config 3) -------------------------------
@@ -304,10 +491,13 @@ struct PairArgs {
     Pose pose;
     StdDev sd;
     uint64_t seed, scene_id, sample_begin, n_samples;
-    uint32_t chunk;  // samples per wave, multiple of 64
+    uint32_t chunk;  // samples per wave, multiple of 256 (whole iterations of wave_count_hits)
 };
 
-__global__ __launch_bounds__(kMcBlock) void mc_pair_kernel(PairArgs A, unsigned long long* __restrict__ d_hits)
+#ifndef C2D_MC_PAIR_WAVES
+#define C2D_MC_PAIR_WAVES 5
+#endif
+__global__ __launch_bounds__(kMcBlock, C2D_MC_PAIR_WAVES) void mc_pair_kernel(PairArgs A, unsigned long long* __restrict__ d_hits)
 {
     __shared__ WaveQueue s_queue[kWavesPerBlock];
     const Scene sc = make_scene(A.robot_w, A.robot_h, A.px, A.py, A.pose, A.sd);
@@ -409,8 +599,11 @@ __global__ void mc_scenes_init_kernel(AdaptiveState* state, uint32_t n_scenes)
 // 6 waves per SIMD (80 VGPRs, two dwords spilled) instead of the 5 the compiler's 81 VGPRs allow: the certain-miss path is a
 // chain of dependent Philox multiplies, and the sixth wave is worth 5 % on the config-4 workload (806.7 -> 765.5 ms per
 // 4e6 data points) and 4 % on the reference-default batch; 8 waves (64 VGPRs, 17 dwords spilled) give nothing more.
+#ifndef C2D_MC_ADV_WAVES
+#define C2D_MC_ADV_WAVES 6
+#endif
 template <bool BURST>
-__global__ __launch_bounds__(kMcBlock, 6) void mc_scenes_advance_kernel(ScenesArgs A)
+__global__ __launch_bounds__(kMcBlock, C2D_MC_ADV_WAVES) void mc_scenes_advance_kernel(ScenesArgs A)
 {
     __shared__ WaveQueue s_queue[kWavesPerBlock];
     const uint32_t n_active = A.state->n_active;
@@ -425,7 +618,7 @@ __global__ __launch_bounds__(kMcBlock, 6) void mc_scenes_advance_kernel(ScenesAr
     uint32_t wps = (A.sched.want_waves + n_active - 1) / n_active;
     wps = wps < 1 ? 1 : (wps > max_split ? max_split : wps);
     uint32_t chunk = (n_batch + wps - 1) / wps;
-    chunk = ((chunk + 63) / 64) * 64;
+    chunk = ((chunk + 255) / 256) * 256;  // whole iterations of wave_count_hits
     wps = (n_batch + chunk - 1) / chunk;
 
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -600,17 +793,20 @@ __global__ void philox_normals_kernel(uint64_t seed, uint64_t scene_id, uint64_t
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const U4 a = philox_block(seed, scene_id, sample_begin + i, 0);
-        const U4 b = philox_block(seed, scene_id, sample_begin + i, 1);
+        // the six words of the sample in draw order (draw layout: c2d_math.hpp)
+        const uint64_t s = sample_begin + i, g = s >> 2;
+        const int j = (int)(s & 3);
+        const U4 b0 = philox_draw_block(seed, scene_id, g, 0), b1 = philox_draw_block(seed, scene_id, g, 1);
+        const U4 b2 = philox_draw_block(seed, scene_id, g, 2 + (j >> 1)), b3 = philox_draw_block(seed, scene_id, g, 4 + (j >> 1));
+        const uint32_t w[6] = {u4_word(b0, j), u4_word(b1, j), (j & 1) ? b2.z : b2.x, (j & 1) ? b2.w : b2.y,
+                               (j & 1) ? b3.z : b3.x, (j & 1) ? b3.w : b3.y};
         float v[6];
-        box_muller(a.x, a.y, v[0], v[1]);
-        box_muller(a.z, a.w, v[2], v[3]);
-        box_muller(b.x, b.y, v[4], v[5]);
+        box_muller(w[0], w[1], v[0], v[1]);
+        box_muller(w[2], w[3], v[2], v[3]);
+        box_muller(w[4], w[5], v[4], v[5]);
         for (int k = 0; k < 5; k++) normals[i * 5 + k] = v[k];
-        if (raw) {
-            raw[i * 8 + 0] = a.x; raw[i * 8 + 1] = a.y; raw[i * 8 + 2] = a.z; raw[i * 8 + 3] = a.w;
-            raw[i * 8 + 4] = b.x; raw[i * 8 + 5] = b.y; raw[i * 8 + 6] = b.z; raw[i * 8 + 7] = b.w;
-        }
+        if (raw)
+            for (int k = 0; k < 6; k++) raw[i * 6 + k] = w[k];
     }
 }
 
@@ -717,8 +913,8 @@ int c2d_mc_pair(c2d_ctx* ctx, float robot_w, float robot_h, const Position* pos,
     // chunk: enough samples per wave to amortise scene set-up, enough waves to fill the chip
     const uint64_t target_waves = (uint64_t)ctx->prop.multiProcessorCount * 32;
     uint64_t chunk = (n_samples + target_waves - 1) / target_waves;
-    chunk = ((chunk + 63) / 64) * 64;
-    if (chunk < 64) chunk = 64;
+    chunk = ((chunk + 255) / 256) * 256;
+    if (chunk < 256) chunk = 256;
     if (chunk > 8192) chunk = 8192;
     A.chunk = (uint32_t)chunk;
     const uint64_t n_chunks = (n_samples + chunk - 1) / chunk;

@@ -186,16 +186,27 @@ int c2d_sat_poly_pairs_rows(c2d_ctx* ctx, const float* d_vx, const float* d_vy, 
 
 /* ---- random stream -----------------------------------------------------------
  * Replaces setup_kernel + curand_normal (utils.cu:111-117, :146-150).  The
- * generator is counter based: Philox4x32-10 with key = seed, counter =
- * (2*sample + j, scene_id), j in {0,1} — identical to rocRAND's
- * rocrand_state_philox4x32_10 initialised with (seed, subsequence = scene_id,
- * offset = 8*sample).  No state array, no set-up kernel, results independent
- * of launch geometry and of how samples are sharded over GPUs.
+ * generator is counter based: Philox4x32-10 with key = seed and subsequence =
+ * scene_id — rocRAND's rocrand_state_philox4x32_10 engine.  No state array, no
+ * set-up kernel, results independent of launch geometry and of how samples are
+ * sharded over GPUs.
+ *
+ * Draw layout.  The samples of a stream are drawn in groups of four: sample s is
+ * member j = s & 3 of group g = s >> 2, which owns blocks 8g .. 8g+5 of the
+ * subsequence (rocRAND: rocrand_init(seed, scene_id, offset = 4 * (8g + b))):
+ *   block 8g+0, word j                  radius word of the first Box-Muller pair (dx, dy)
+ *   block 8g+1, word j                  angle word of that pair
+ *   block 8g+2+(j>>1), words 2(j&1)..   radius, angle word of the second pair (dtheta, dw)
+ *   block 8g+4+(j>>1), words 2(j&1)..   third pair (dh; its second normal is unused)
+ * The draw ORDER per sample is the reference's (dx, dy, dtheta, dw, dh).  Grouping
+ * the four radius words of four samples in one block is what lets the kernels
+ * prove "certain miss" for most samples of a far scene at a quarter of a Philox
+ * block per sample.
  *
  * c2d_philox_normals (parity/debug): for samples sample_begin .. +n writes the
  * five N(0,1) draws in the reference's order dx,dy,dtheta,dw,dh
- * (utils.cu:146-150) to d_normals[n][5] and, if d_raw != NULL, the eight raw
- * 32-bit words to d_raw[n][8]. */
+ * (utils.cu:146-150) to d_normals[n][5] and, if d_raw != NULL, the six raw
+ * 32-bit words in draw order to d_raw[n][6]. */
 int c2d_philox_normals(c2d_ctx* ctx, uint64_t seed, uint64_t scene_id, uint64_t sample_begin,
                        size_t n, float* d_normals, uint32_t* d_raw, c2d_stream stream);
 

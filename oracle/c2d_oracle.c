@@ -21,7 +21,7 @@
  *   D1  calcSlack squares the hit count in 64-bit (utils.cu:194 overflows int);
  *   D2  getBin stops at n_bins-1 (utils.cu:201-202 reads one past the end);
  *   RNG cuRAND XORWOW cannot be reproduced without CUDA; the stream is
- *       Philox4x32-10 keyed by (seed, scene, sample) — see c2d_oracle_normals5;
+ *       Philox4x32-10 keyed by (seed, scene, sample group) — see c2d_oracle_draw_words;
  *   sin/cos/log are the c2d polynomial forms instead of CUDA's libdevice.
  */
 #define _GNU_SOURCE
@@ -186,8 +186,9 @@ void c2d_oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-/* The eight raw words of sample `sample` of stream (seed, scene_id): blocks
- * 2*sample and 2*sample+1 of subsequence scene_id. */
+/* The eight raw words of item `sample` of stream (seed, scene_id): blocks
+ * 2*sample and 2*sample+1 of subsequence scene_id (the scene sampler's layout,
+ * c2d_oracle_sample_scenes; also the rocRAND engine pin of tests/test_boundary.py). */
 void c2d_oracle_raw8(uint64_t seed, uint64_t scene_id, uint64_t sample, uint32_t raw[8])
 {
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
@@ -197,6 +198,62 @@ void c2d_oracle_raw8(uint64_t seed, uint64_t scene_id, uint64_t sample, uint32_t
     blk += 1;
     ctr[0] = (uint32_t)blk; ctr[1] = (uint32_t)(blk >> 32);
     c2d_oracle_philox4x32_10(ctr, key, raw + 4);
+}
+
+/* Draw layout of the Monte-Carlo loop.  The samples of a stream (seed, scene_id)
+ * are drawn in groups of four: sample s is member j = s & 3 of group g = s >> 2,
+ * which owns Philox blocks 8g .. 8g+5 of subsequence scene_id:
+ *   block 8g+0 word j        radius word of the sample's first Box-Muller pair (dx, dy)
+ *   block 8g+1 word j        angle word of that pair
+ *   block 8g+2 + (j >> 1)    words 2(j&1), 2(j&1)+1: radius, angle word of the second pair (dtheta, dw)
+ *   block 8g+4 + (j >> 1)    words 2(j&1), 2(j&1)+1: third pair (dh, second normal unused)
+ * (blocks 8g+6, 8g+7 are unused).  The layout is a choice of this build — the
+ * reference's XORWOW stream is not reproducible without CUDA anyway — made so
+ * that the four radius words of a group come out of ONE Philox block. */
+static void draw_group_block(uint64_t seed, uint64_t scene_id, uint64_t group, uint32_t b, uint32_t out[4])
+{
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint64_t blk = 8 * group + b;
+    uint32_t ctr[4] = {(uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)scene_id, (uint32_t)(scene_id >> 32)};
+    c2d_oracle_philox4x32_10(ctr, key, out);
+}
+
+/* The six words of one sample in draw order: radius1, angle1, radius2, angle2, radius3, angle3. */
+void c2d_oracle_draw_words(uint64_t seed, uint64_t scene_id, uint64_t sample, uint32_t w[6])
+{
+    uint64_t g = sample >> 2;
+    uint32_t j = (uint32_t)(sample & 3), h = j >> 1, o = 2 * (j & 1);
+    uint32_t b[4];
+    draw_group_block(seed, scene_id, g, 0, b); w[0] = b[j];
+    draw_group_block(seed, scene_id, g, 1, b); w[1] = b[j];
+    draw_group_block(seed, scene_id, g, 2 + h, b); w[2] = b[o]; w[3] = b[o + 1];
+    draw_group_block(seed, scene_id, g, 4 + h, b); w[4] = b[o]; w[5] = b[o + 1];
+}
+
+/* The same words for consecutive samples without recomputing a group's blocks
+ * (the loops below walk samples in order; one cache per thread). */
+typedef struct {
+    uint64_t group;
+    int valid;          /* bit b: blk[b] holds block 8*group + b */
+    uint32_t blk[6][4];
+} DrawCache;
+
+static inline const uint32_t* cached_block(DrawCache* c, uint64_t seed, uint64_t scene_id, uint64_t g, uint32_t b)
+{
+    if (c->group != g) { c->group = g; c->valid = 0; }
+    if (!(c->valid & (1 << b))) { draw_group_block(seed, scene_id, g, b, c->blk[b]); c->valid |= 1 << b; }
+    return c->blk[b];
+}
+
+static void draw_words_cached(DrawCache* c, uint64_t seed, uint64_t scene_id, uint64_t sample, uint32_t w[6])
+{
+    uint64_t g = sample >> 2;
+    uint32_t j = (uint32_t)(sample & 3), h = j >> 1, o = 2 * (j & 1);
+    const uint32_t* b;
+    b = cached_block(c, seed, scene_id, g, 0); w[0] = b[j];
+    b = cached_block(c, seed, scene_id, g, 1); w[1] = b[j];
+    b = cached_block(c, seed, scene_id, g, 2 + h); w[2] = b[o]; w[3] = b[o + 1];
+    b = cached_block(c, seed, scene_id, g, 4 + h); w[4] = b[o]; w[5] = b[o + 1];
 }
 
 /* Box-Muller on two 32-bit words: x -> radius, y -> angle; first normal uses
@@ -215,12 +272,12 @@ void c2d_oracle_box_muller(uint32_t x, uint32_t y, float* n0, float* n1)
  * dx, dy, dtheta, dw, dh (utils.cu:146-150). */
 void c2d_oracle_normals5(uint64_t seed, uint64_t scene_id, uint64_t sample, float n[5])
 {
-    uint32_t raw[8];
+    uint32_t w[6];
     float unused;
-    c2d_oracle_raw8(seed, scene_id, sample, raw);
-    c2d_oracle_box_muller(raw[0], raw[1], &n[0], &n[1]);
-    c2d_oracle_box_muller(raw[2], raw[3], &n[2], &n[3]);
-    c2d_oracle_box_muller(raw[4], raw[5], &n[4], &unused);
+    c2d_oracle_draw_words(seed, scene_id, sample, w);
+    c2d_oracle_box_muller(w[0], w[1], &n[0], &n[1]);
+    c2d_oracle_box_muller(w[2], w[3], &n[2], &n[3]);
+    c2d_oracle_box_muller(w[4], w[5], &n[4], &unused);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -469,13 +526,19 @@ static void scene_setup(float robot_w, float robot_h, const Position* pos, const
     c2d_oracle_rot_trans_rectangle(robot, pos->x, pos->y, pose->theta);
 }
 
-/* One sample: compute_collision_probability.cu:137-138 */
+/* One sample: compute_collision_probability.cu:137-138 (all five normals are
+ * drawn, as in utils.cu:146-150, whatever the standard deviations are). */
 static inline int scene_sample(const float robot[8], const float obstacle[8], const StdDev* sd,
-                               uint64_t seed, uint64_t scene_id, uint64_t sample)
+                               uint64_t seed, uint64_t scene_id, uint64_t sample, DrawCache* cache)
 {
     float n[5];
     float sampled[8];
-    c2d_oracle_normals5(seed, scene_id, sample, n);
+    uint32_t w[6];
+    float unused;
+    draw_words_cached(cache, seed, scene_id, sample, w);
+    c2d_oracle_box_muller(w[0], w[1], &n[0], &n[1]);
+    c2d_oracle_box_muller(w[2], w[3], &n[2], &n[3]);
+    c2d_oracle_box_muller(w[4], w[5], &n[4], &unused);
     c2d_oracle_sample_rectangle(obstacle, sampled, sd, n);
     return c2d_oracle_convex_collide(robot, sampled);
 }
@@ -488,9 +551,13 @@ unsigned long long c2d_oracle_mc_pair(float robot_w, float robot_h, const Positi
     float robot[8], obstacle[8];
     scene_setup(robot_w, robot_h, pos, pose, robot, obstacle);
     unsigned long long hits = 0;
-#pragma omp parallel for schedule(static) reduction(+ : hits)
-    for (long long i = 0; i < (long long)n_samples; i++)
-        hits += (unsigned)scene_sample(robot, obstacle, sd, seed, scene_id, sample_begin + (uint64_t)i);
+#pragma omp parallel reduction(+ : hits)
+    {
+        DrawCache cache = {~0ull, 0, {{0}}};
+#pragma omp for schedule(static)
+        for (long long i = 0; i < (long long)n_samples; i++)
+            hits += (unsigned)scene_sample(robot, obstacle, sd, seed, scene_id, sample_begin + (uint64_t)i, &cache);
+    }
     return hits;
 }
 
@@ -536,9 +603,10 @@ unsigned long long c2d_oracle_mc_scenes(const Pose* poses, uint32_t num_poses, c
         scene_setup(robot_w, robot_h, &pos, &pose, robot, obstacle);
         uint64_t sid = scene_id_base + (uint64_t)g;
         uint32_t n = 0, k = 0;
+        DrawCache cache = {~0ull, 0, {{0}}};
         while (n < max_samples) { /* ccp.cu:281 (num_left > 0 is this scene not being done) */
             uint32_t nb = n < switch_at ? small_batch : large_batch; /* ccp.cu:283-286; ztest.cu:332 constant */
-            for (uint32_t i = 0; i < nb; i++) k += (uint32_t)scene_sample(robot, obstacle, &sd, seed, sid, (uint64_t)n + i);
+            for (uint32_t i = 0; i < nb; i++) k += (uint32_t)scene_sample(robot, obstacle, &sd, seed, sid, (uint64_t)n + i, &cache);
             n += nb;
             float slack = c2d_oracle_calc_slack(n, k);               /* ccp.cu:140 */
             float p = (float)k / (float)n;                          /* ccp.cu:142 */

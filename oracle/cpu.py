@@ -178,6 +178,17 @@ def raw8(seed, scene_id, sample_begin, n):
     return out
 
 
+def draw_words(seed, scene_id, sample_begin, n):
+    """The six raw words of each sample in draw order (radius1, angle1, radius2, angle2, radius3, angle3):
+    the group-of-four draw layout of the Monte-Carlo loop (c2d_oracle.c, c2d_oracle_draw_words)."""
+    out = np.empty((n, 6), np.uint32)
+    L = lib()
+    for i in range(n):
+        L.c2d_oracle_draw_words(C.c_uint64(seed), C.c_uint64(scene_id), C.c_uint64(sample_begin + i),
+                                out[i].ctypes.data_as(C.POINTER(C.c_uint32)))
+    return out
+
+
 def normals5(seed, scene_id, sample_begin, n):
     out = np.empty((n, 5), np.float32)
     L = lib()

@@ -80,10 +80,12 @@ def main():
 
     # ---- random stream: raw Philox words and normals ---------------------------------------
     seed, scene = 0x0123456789ABCDEF, 0xFEDCBA9876543210
-    raw = cpu.raw8(seed, scene, (1 << 33) - 4, 16)  # crosses the 32-bit counter carry
-    nrm = cpu.normals5(seed, scene, (1 << 33) - 4, 16)
+    begin = (1 << 31) - 6  # the block counter 8 * (sample >> 2) + b crosses its 32-bit carry inside the run
+    raw = cpu.raw8(seed, scene, (1 << 33) - 4, 16)  # scene-sampler layout (blocks 2s, 2s + 1), crosses the carry too
+    words = cpu.draw_words(seed, scene, begin, 16)
+    nrm = cpu.normals5(seed, scene, begin, 16)
     np.savez_compressed(os.path.join(HERE, "philox_stream.npz"), seed=np.uint64(seed), scene=np.uint64(scene),
-                        sample_begin=np.uint64((1 << 33) - 4), raw=raw, normals=nrm)
+                        sample_begin=np.uint64(begin), raw=raw, raw_begin=np.uint64((1 << 33) - 4), draw_words=words, normals=nrm)
     print("philox_stream.npz: 16 samples")
 
     # ---- MC: fixed scenes, exact hit counts ---------------------------------------------------

@@ -76,8 +76,8 @@ def test_host_stat_helpers_match_oracle(pkg, oracle):
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc + rocRAND headers")
 def test_stream_is_rocrand_philox(tmp_path, oracle):
-    """The c2d stream (seed, scene, sample) equals rocrand_state_philox4x32_10 with
-    rocrand_init(seed, subsequence=scene, offset=8*sample) — checked by running
+    """The c2d streams are rocrand_state_philox4x32_10 with rocrand_init(seed, subsequence=scene, offset): offset =
+    8*item for the scene sampler's layout, 4*(8*group + block) for the Monte-Carlo draws — checked by running
     rocRAND's own __host__ __device__ engine on the host."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     exe = tmp_path / "rocrand_stream"
@@ -87,8 +87,12 @@ def test_stream_is_rocrand_philox(tmp_path, oracle):
         out = subprocess.run([str(exe), str(seed), str(scene), str(sample), "8"], check=True, capture_output=True, text=True).stdout
         ref = np.array([[int(v) for v in line.split()] for line in out.strip().splitlines()], np.uint32)
         assert np.array_equal(oracle.raw8(seed, scene, sample, 8), ref)
-    # "rocRAND replacing curand": the five normals of a sample are rocRAND's own rocrand_normal4 / rocrand_normal of the
-    # same state up to the rounding of the math functions (c2d fixes bit-reproducible log / sqrt / sincos forms and centres
+        # the Monte-Carlo loop's draw layout (groups of four samples): the same engine at offset 4 * (8 * group + block)
+        out = subprocess.run([str(exe), str(seed), str(scene), str(sample), "9", "draws"], check=True, capture_output=True, text=True).stdout
+        ref = np.array([[int(v) for v in line.split()] for line in out.strip().splitlines()], np.uint32)
+        assert np.array_equal(oracle.draw_words(seed, scene, sample, 9), ref)
+    # "rocRAND replacing curand": the five normals of a sample are rocRAND's own Box-Muller (rocrand_normal2's) of the
+    # same words up to the rounding of the math functions (c2d fixes bit-reproducible log / sqrt / sincos forms and centres
     # the uniform at (x + 1/2) / 2^32 where rocRAND uses (x + 1) / 2^32; glibc / OCML differ between host and device anyway)
     out = subprocess.run([str(exe), "1234", "77", "1000", "4000", "normals"], check=True, capture_output=True, text=True).stdout
     theirs = np.array([[float(v) for v in line.split()] for line in out.strip().splitlines()], np.float64)

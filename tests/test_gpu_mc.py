@@ -25,16 +25,16 @@ def gpu_hits(eng, pos, pose, sd, seed, scene, begin, n, robot=(W, H)):
 def test_philox_stream_golden_and_oracle(eng, oracle):
     g = np.load(os.path.join(GOLD, "philox_stream.npz"))
     seed, scene, begin = int(g["seed"]), int(g["scene"]), int(g["sample_begin"])
-    d_n, d_r = eng.empty((16, 5), np.float32), eng.empty((16, 8), np.uint32)
+    d_n, d_r = eng.empty((16, 5), np.float32), eng.empty((16, 6), np.uint32)
     eng.philox_normals(seed, scene, begin, 16, d_n, d_r)
-    assert np.array_equal(d_r.get(), g["raw"])
+    assert np.array_equal(d_r.get(), g["draw_words"])
     assert np.array_equal(d_n.get().view(np.uint32), g["normals"].view(np.uint32))
     # a longer run against the live oracle, bit for bit
     n = 50000
-    d_n, d_r = eng.empty((n, 5), np.float32), eng.empty((n, 8), np.uint32)
-    eng.philox_normals(99, 12345, 10**12, n, d_n, d_r)
-    assert np.array_equal(d_r.get(), oracle.raw8(99, 12345, 10**12, n))
-    assert np.array_equal(d_n.get().view(np.uint32), oracle.normals5(99, 12345, 10**12, n).view(np.uint32))
+    d_n, d_r = eng.empty((n, 5), np.float32), eng.empty((n, 6), np.uint32)
+    eng.philox_normals(99, 12345, 10**12 + 1, n, d_n, d_r)  # starts inside a group of four
+    assert np.array_equal(d_r.get(), oracle.draw_words(99, 12345, 10**12 + 1, n))
+    assert np.array_equal(d_n.get().view(np.uint32), oracle.normals5(99, 12345, 10**12 + 1, n).view(np.uint32))
 
 
 def _math_both(eng, oracle, fn, bits):

@@ -101,10 +101,32 @@ def test_philox_known_answer(oracle):
 
 def test_philox_stream_golden(oracle):
     g = np.load(os.path.join(GOLD, "philox_stream.npz"))
-    raw = oracle.raw8(int(g["seed"]), int(g["scene"]), int(g["sample_begin"]), 16)
+    raw = oracle.raw8(int(g["seed"]), int(g["scene"]), int(g["raw_begin"]), 16)
+    words = oracle.draw_words(int(g["seed"]), int(g["scene"]), int(g["sample_begin"]), 16)
     nrm = oracle.normals5(int(g["seed"]), int(g["scene"]), int(g["sample_begin"]), 16)
     assert np.array_equal(raw, g["raw"])
+    assert np.array_equal(words, g["draw_words"])
     assert np.array_equal(nrm.view(np.uint32), g["normals"].view(np.uint32))
+
+
+def test_draw_layout_is_groups_of_four(oracle):
+    """Sample s = 4g + j takes word j of blocks 8g and 8g+1 (first Box-Muller pair), words 2(j&1).. of block 8g+2+(j>>1)
+    (second pair) and of block 8g+4+(j>>1) (third pair) — restated here straight from the Philox block function."""
+    seed, scene = 0xDEADBEEFCAFEF00D, 0x123456789
+    key = [seed & 0xffffffff, seed >> 32]
+    for s0 in (0, 5, (1 << 40) + 3):
+        words = oracle.draw_words(seed, scene, s0, 9)
+        for i in range(9):
+            s = s0 + i
+            g, j = s >> 2, s & 3
+
+            def block(b):
+                blk = 8 * g + b
+                return oracle.philox([blk & 0xffffffff, blk >> 32, scene & 0xffffffff, scene >> 32], key)
+
+            o = 2 * (j & 1)
+            want = [block(0)[j], block(1)[j], block(2 + (j >> 1))[o], block(2 + (j >> 1))[o + 1], block(4 + (j >> 1))[o], block(4 + (j >> 1))[o + 1]]
+            assert words[i].tolist() == [int(v) for v in want]
 
 
 def test_normals_are_standard_normal(oracle):
