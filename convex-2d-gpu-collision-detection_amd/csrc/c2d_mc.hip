@@ -201,7 +201,7 @@ C2D_DEV bool sample_collides(const Scene& sc, const float (&o)[8])
 #define C2D_MC_ILP 2
 #endif
 #ifndef C2D_MC_FAR_X0
-#define C2D_MC_FAR_X0 0x40000000u  // a quarter of the radius words are candidates
+#define C2D_MC_FAR_X0 0x80000000u  // half of the radius words are candidates (config-4 shard: 446 / 422 / 401 ms for 2^29 / 2^30 / 2^31)
 #endif
 [[maybe_unused]] constexpr uint32_t kFarX0 = C2D_MC_FAR_X0;
 [[maybe_unused]] constexpr int kIlp = C2D_MC_ILP;  // radius blocks computed side by side on the far-scene path
@@ -211,7 +211,7 @@ constexpr int kCandSlots = 64 + 256 * C2D_MC_ILP;  // < 64 left over + every sam
 // Per-wave LDS.  Two ways to run a scene, chosen per scene (wave-uniform):
 //  * NEAR (the radius word proves little or nothing): a lane owns a group of four samples and shares the group's Philox
 //    blocks among them; samples the centre pretest cannot rule out are parked in `cw/idx` and evaluated 64 at a time.
-//  * FAR (the radius word alone proves at least three samples in four to be misses): the four radius words of a group
+//  * FAR (the radius word alone proves at least every other sample to be a miss): the four radius words of a group
 //    cost one Philox block, and everything after that works on COMPACTED samples, 64 busy lanes at a time:
 //    candidates (radius word, offset) wait in `cand` for their angle word / Box-Muller / centre pretest, the undecided
 //    ones among them in `und` for the full evaluation.  Each of these later stages draws the block it needs per sample.
@@ -360,8 +360,8 @@ C2D_DEV uint32_t wave_count_hits_near(const Scene& sc, uint64_t seed, uint64_t s
 }
 
 #ifndef C2D_MC_NO_PRETEST
-// ---- FAR: the same count for a scene whose radius test (make_scene: raw word >= x0 proves the miss) passes at most one
-// sample in four.  Three stages, each on 64 busy lanes, each present once in the code:
+// ---- FAR: the same count for a scene whose radius test (make_scene: raw word >= x0 proves the miss) passes at most every
+// other sample.  Three stages, each on 64 busy lanes, each present once in the code:
 //   1  radius blocks: one Philox block per group of four samples, kIlp iterations (256 samples each) side by side —
 //      independent multiply chains per lane — until 64 candidates wait or the input ends; an iteration without a
 //      candidate costs nothing beyond its block;

@@ -121,6 +121,21 @@ def test_mc_centre_pretest_boundary_sweep(eng, oracle):
     assert cases == 4 * 3 * 12
 
 
+def test_mc_far_and_near_paths_unaligned_ranges(eng, oracle):
+    """The kernels run a scene in one of two ways — groups of four samples per lane (near), or compacted candidates of the
+    radius test (far; csrc/c2d_mc.hip) — chosen from the scene's candidate fraction.  Distances from overlapping to far
+    apart cross that switch; sample ranges start and end anywhere inside a group of four."""
+    sd = (0.3, 0.25, 0.2, 0.0, 0.1)
+    pose = (2.0, 1.0, 0.4)
+    k = 0
+    for dist in (0.5, 2.0, 3.0, 3.5, 4.0, 4.5, 5.0, 5.5, 6.0, 7.0, 9.0, 14.0):
+        for begin, n in ((1, 70_001), (4 * 12345 + 2, 33_333), ((1 << 40) + 3, 2_047), (7, 3), (6, 257)):
+            pos = (dist * 0.8, dist * 0.6)
+            got = gpu_hits(eng, pos, pose, sd, 31337, 100 + k, begin, n)
+            assert got == oracle.mc_pair(W, H, pos, pose, sd, 31337, 100 + k, begin, n), (dist, begin, n)
+            k += 1
+
+
 @pytest.mark.parametrize("robot,pos,pose,sd", [
     ((4.07, 1.74), (0.0, 0.0), (2.0, 1.0, 0.3), (0.0, 0.0, 0.0, 0.0, 0.0)),        # no noise at all, overlapping: p = 1
     ((4.07, 1.74), (9.0, 0.0), (2.0, 1.0, 0.3), (0.0, 0.0, 0.0, 0.0, 0.0)),        # no noise, apart: p = 0
