@@ -168,9 +168,11 @@ C2D_DEV void sample_obstacle(const Scene& sc, uint32_t radius_word, uint32_t ang
 // convex_collide(robot, obstacle) (utils.cu:159-184).  All eight axes are part
 // of the result; the remaining axes are skipped only when every lane of the
 // wave is already separated, which cannot change any lane's answer.  The
-// wave-wide check (one ballot + scalar branch) sits after axes 2, 4 and 6: far
-// scenes (p ~ 0, the bulk of an adaptive run's samples) leave after two robot
-// axes, near scenes pay three scalar branches.
+// wave-wide check (one ballot + scalar branch) sits after axes 2, 4 and 6: the
+// undecided samples of far and low-p scenes are mostly misses and leave early, a scene
+// with p ~ 0.5 pays three scalar branches (config-3 scene 0.620 -> 0.605 ms without them, but
+// the config-4 shard 401 -> 410 ms; making the later checks depend on the first one's count
+// costs what it saves on both).
 #ifndef C2D_MC_EARLY_MASK
 #define C2D_MC_EARLY_MASK 0x2A  // bit i set: check after axis i+1 (axes 0-3 robot, 4-7 obstacle)
 #endif
@@ -198,7 +200,7 @@ C2D_DEV bool sample_collides(const Scene& sc, const float (&o)[8])
 #define C2D_MC_PRETEST_HOLDOFF 3
 #endif
 #ifndef C2D_MC_ILP
-#define C2D_MC_ILP 2
+#define C2D_MC_ILP 1  // 1, 2, 3 blocks side by side: 425 / 422 / 453 ms on the config-4 shard; 1 keeps the LDS at 4.5 KB per wave
 #endif
 #ifndef C2D_MC_FAR_X0
 #define C2D_MC_FAR_X0 0x80000000u  // half of the radius words are candidates (config-4 shard: 446 / 422 / 401 ms for 2^29 / 2^30 / 2^31)
@@ -225,7 +227,6 @@ struct WaveQueue {
             // samples, and 16 registers of state held over that evaluation cost the kernel its sixth wave per SIMD
             uint32_t r[4][64];           // radius block (block 0 of the groups)
             uint32_t a[4][64];           // angle block (block 1)
-            uint32_t p[4][64];           // block 2 / 3: second Box-Muller pairs of members 0,1 / 2,3
         } near;
         struct {
             uint2 cand[kCandSlots];      // radius word, sample offset within the chunk
@@ -240,10 +241,10 @@ struct WaveQueue {
 // j = 0..3 handles member j of the 64 groups.  begin and count are arbitrary (a shard may start inside a group):
 // positions outside [begin, begin + count) are masked, never drawn into the result.
 //
-// The body is one loop around a small state machine — open an iteration / produce a sub-iteration / evaluate 64 samples —
-// so that each expensive piece (Box-Muller of the centre, the full evaluation) exists ONCE in the kernel's code: unrolled
-// over j the kernel was 90 KB, more than the instruction cache holds, and ran 30 % slower than the one-sample-per-lane
-// kernel it replaced.
+// The sub-iterations are a rolled loop, and the final flush of the queue runs through the same loop body, so that each
+// expensive piece (Box-Muller of the centre, the full evaluation) exists ONCE in the kernel's code: unrolled over j the
+// kernel was 90 KB, more than the instruction cache holds, and ran 30 % slower than the one-sample-per-lane kernel it
+// replaced.
 C2D_DEV uint32_t wave_count_hits_near(const Scene& sc, uint64_t seed, uint64_t scene_id, uint64_t begin, uint32_t count,
                                       WaveQueue& wq)
 {
@@ -257,104 +258,117 @@ C2D_DEV uint32_t wave_count_hits_near(const Scene& sc, uint64_t seed, uint64_t s
     const uint32_t base = (uint32_t)(begin & 3);           // position of sample `begin` inside it
     const uint32_t end_pos = base + count;                 // this call's samples are positions [base, end_pos) from 4 * g0
     const uint32_t n_groups = (end_pos + 3) >> 2;
-
-    uint32_t gi = 0;      // next group offset to open
-    // the iteration being produced (all wave-uniform)
-    uint32_t cgi = 0;     // its group offset
-    bool have = false;    // q.p holds block 2 (j < 2) / 3 (j >= 2) of the lanes' groups
-    uint32_t j = 4;       // next sub-iteration; 4: no iteration open
-    uint32_t lo = 0, hi = 0;
     auto stash = [&](uint32_t (&dst)[4][64], const U4& v) { dst[0][lane] = v.x; dst[1][lane] = v.y; dst[2][lane] = v.z; dst[3][lane] = v.w; };
 
+    uint32_t gi = 0;      // next group offset to open
+    bool flush = false;   // input exhausted: the loop body only drains the queue
     for (;;) {
-        bool direct = false;  // evaluate this sub-iteration's samples straight from the registers
-        float dx = 0.0f, dy = 0.0f;
-        uint32_t w2r = 0, w2a = 0, sidx = 0;
-        bool live = false;
-        if (j < 4) {
-            // ---- produce sub-iteration j: member j of the 64 groups
-            if (j == 2) have = false;
-            const uint32_t pos = 4 * lane + j;
-            const bool in_range = pos >= lo && pos < hi;
-            const uint32_t rw = q.r[j][lane];
-            const uint32_t odd2 = 2 * (j & 1);
-            const uint32_t half = j >> 1;
-            sidx = 4 * cgi - base + pos;   // chunk offset (wraps only where masked)
-            j++;
-            bool undecided = in_range;
-            if (dense) {  // every lane needs the full evaluation anyway
-                dense--;
-                sample_centre(sc, rw, q.a[j - 1][lane], dx, dy);
-                live = in_range;
-                direct = true;
-            } else {
-#ifndef C2D_MC_NO_PRETEST
-                undecided = in_range && !(sc.use_x0 && rw >= sc.x0);   // the radius word alone may prove the miss
-                if (__ballot(undecided) == 0ull) continue;
-#endif
-                sample_centre(sc, rw, q.a[j - 1][lane], dx, dy);
-#ifndef C2D_MC_NO_PRETEST
-                undecided = undecided && !centre_pretest(sc, dx, dy);
-#endif
-            }
-            const unsigned long long m = __ballot(undecided);
-            if (!direct) {
-                if (m == 0ull) continue;  // 64 certain misses
-                if (m == ~0ull) dense = C2D_MC_PRETEST_HOLDOFF;
-            }
-            if (!have) { stash(q.p, philox_draw_block(seed, scene_id, g0 + cgi + lane, 2 + half)); have = true; }
-            w2r = q.p[odd2][lane];
-            w2a = q.p[odd2 + 1][lane];
-            if (!direct) {
-                if (undecided) {
-                    const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    q.cw[slot] = make_float4(dx, dy, __uint_as_float(w2r), __uint_as_float(w2a));
-                    q.idx[slot] = sidx;
-                }
-                qn += (uint32_t)__popcll(m);
-                if (qn < 64) continue;
-            }
-        } else if (gi < n_groups) {
+        uint32_t lo = 0, hi = 0;
+        bool inner = false;   // every position of the iteration is in range
+        uint64_t g = 0;       // the lane's group
+        uint32_t sidx0 = 0;   // chunk offset of its member 0 (wraps only where masked)
+        if (gi < n_groups) {
             // ---- open the next iteration: radius and angle blocks of its 64 groups
-            cgi = gi;
-            gi += 64;
-            const uint32_t p0 = 4 * cgi;                                  // position of the iteration's first sample
+            const uint32_t p0 = 4 * gi;                                   // position of the iteration's first sample
             lo = p0 >= base ? 0u : base;                                   // (p0 < base only for the first iteration)
             const uint32_t rem = end_pos - p0;
             hi = rem < 256 ? rem : 256u;
-            stash(q.r, philox_draw_block(seed, scene_id, g0 + cgi + lane, 0));
-            stash(q.a, philox_draw_block(seed, scene_id, g0 + cgi + lane, 1));
-            have = false;
-            j = 0;
-            continue;
+            inner = lo == 0 && hi == 256;
+            g = g0 + gi + lane;
+            sidx0 = p0 - base + 4 * lane;
+            stash(q.r, philox_draw_block(seed, scene_id, g, 0));
+            stash(q.a, philox_draw_block(seed, scene_id, g, 1));
+            gi += 64;
         } else if (qn == 0) {
             break;
+        } else {
+            flush = true;
         }
-        // ---- evaluate 64 samples: this sub-iteration's (direct) or queued ones (a full wave of them, or what is left
-        // at the end).  Lanes read slots that other lanes of this wave wrote: LDS operations of a wave complete in
-        // order, the fence pairs only stop the compiler from reordering the reads above the writes and later writes
-        // above the reads (no instruction is emitted)
-        if (!direct) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const uint32_t take = qn < 64 ? qn : 64;
-            live = lane < take;
-            const uint32_t src = qn - take + (live ? lane : 0);
-            const float4 e = q.cw[src];
-            sidx = q.idx[src];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            qn -= take;
-            dx = e.x;
-            dy = e.y;
-            w2r = __float_as_uint(e.z);
-            w2a = __float_as_uint(e.w);
+        uint32_t pz = 0, pw = 0;  // the odd member's words of block 2 (j = 1) / 3 (j = 3), left by the even member
+        bool have = false;
+#pragma nounroll
+        for (uint32_t j = 0; j < 4; j++) {
+            bool direct = false;  // evaluate this sub-iteration's samples straight from the registers
+            float dx = 0.0f, dy = 0.0f;
+            uint32_t w2r = 0, w2a = 0, sidx = 0;
+            bool live = false;
+            if (!flush) {
+                // ---- produce sub-iteration j: member j of the 64 groups
+                if (j == 2) have = false;
+                const uint32_t pos = 4 * lane + j;
+                const bool in_range = inner || (pos >= lo && pos < hi);
+                const uint32_t rw = q.r[j][lane], aw = q.a[j][lane];
+                const bool odd = (j & 1) != 0;
+                sidx = sidx0 + j;
+                bool undecided = in_range;
+                if (dense) {  // every lane needs the full evaluation anyway
+                    dense--;
+                    sample_centre(sc, rw, aw, dx, dy);
+                    live = in_range;
+                    direct = true;
+                } else {
+#ifndef C2D_MC_NO_PRETEST
+                    undecided = in_range && !(sc.use_x0 && rw >= sc.x0);   // the radius word alone may prove the miss
+                    if (__ballot(undecided) == 0ull) continue;
+#endif
+                    sample_centre(sc, rw, aw, dx, dy);
+#ifndef C2D_MC_NO_PRETEST
+                    undecided = undecided && !centre_pretest(sc, dx, dy);
+#endif
+                }
+                const unsigned long long m = __ballot(undecided);
+                if (!direct) {
+                    if (m == 0ull) continue;  // 64 certain misses
+                    if (m == ~0ull) dense = C2D_MC_PRETEST_HOLDOFF;
+                }
+                if (!have) {
+                    const U4 pb = philox_draw_block(seed, scene_id, g, 2 + (j >> 1));
+                    have = true;
+                    w2r = odd ? pb.z : pb.x;
+                    w2a = odd ? pb.w : pb.y;
+                    pz = pb.z;
+                    pw = pb.w;
+                } else {  // the even member of the pair computed the block
+                    w2r = pz;
+                    w2a = pw;
+                }
+                if (!direct) {
+                    if (undecided) {
+                        const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        q.cw[slot] = make_float4(dx, dy, __uint_as_float(w2r), __uint_as_float(w2a));
+                        q.idx[slot] = sidx;
+                    }
+                    qn += (uint32_t)__popcll(m);
+                    if (qn < 64) continue;
+                }
+            }
+            // ---- evaluate 64 samples: this sub-iteration's (direct) or queued ones (a full wave of them, or what is
+            // left at the end).  Lanes read slots that other lanes of this wave wrote: LDS operations of a wave complete
+            // in order, the fence pairs only stop the compiler from reordering the reads above the writes and later
+            // writes above the reads (no instruction is emitted)
+            if (!direct) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t take = qn < 64 ? qn : 64;
+                live = lane < take;
+                const uint32_t src = qn - take + (live ? lane : 0);
+                const float4 e = q.cw[src];
+                sidx = q.idx[src];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                qn -= take;
+                dx = e.x;
+                dy = e.y;
+                w2r = __float_as_uint(e.z);
+                w2a = __float_as_uint(e.w);
+            }
+            float o[8];
+            sample_obstacle(sc, w2r, w2a, dx, dy, seed, scene_id, begin + sidx, o);
+            hits += (uint32_t)__popcll(__ballot(sample_collides(sc, o) && live));
+            if (flush) break;
         }
-        float o[8];
-        sample_obstacle(sc, w2r, w2a, dx, dy, seed, scene_id, begin + sidx, o);
-        hits += (uint32_t)__popcll(__ballot(sample_collides(sc, o) && live));
     }
     return hits;
 }
