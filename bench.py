@@ -485,7 +485,7 @@ def main() -> None:
                                       "peak": VALU_PEAK_TLANE, "unit": "T VALU lane-instr/s per GPU", "frac": round(lane / VALU_PEAK_TLANE, 4),
                                       "valu_instr_per_sample": c["valu_instr_per_sample"], "instr_source": c.get("source"),
                                       "note": "instructions per DRAWN sample: most samples of this workload are certain misses decided from "
-                                              "one Philox block (DESIGN.md §5); ~0 HBM bytes per sample"}
+                                              "their radius word, four words per Philox block (DESIGN.md §5); ~0 HBM bytes per sample"}
         for a_ in (d_p, d_s, d_sc, d_h, d_u):
             a_.free()
 
