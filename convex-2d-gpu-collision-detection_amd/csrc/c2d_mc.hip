@@ -124,11 +124,14 @@ C2D_DEV Scene make_scene(float robot_w, float robot_h, float px, float py, const
 
 // true: this sample certainly does not collide (proof in make_scene); false: unknown.
 // Non-finite thresholds compare false, i.e. "unknown".
-C2D_DEV bool centre_pretest(const Scene& sc, float dx, float dy)
+C2D_DEV bool centre_pretest(const Scene& sc, float dx, float dy, unsigned long long& miss_m)
 {
     const float t0 = fma_(sc.pax[0], dx, sc.pay[0] * dy);
     const float t1 = fma_(sc.pax[1], dx, sc.pay[1] * dy);
-    return (t0 > sc.phi[0]) | (t0 < sc.plo[0]) | (t1 > sc.phi[1]) | (t1 < sc.plo[1]);
+    const bool a = t0 > sc.phi[0], b = t0 < sc.plo[0], c = t1 > sc.phi[1], d = t1 < sc.plo[1];
+    // the same vote as a lane mask, from the bare comparisons (see sample_collides_mask)
+    miss_m = __builtin_amdgcn_ballot_w64(a) | __builtin_amdgcn_ballot_w64(b) | __builtin_amdgcn_ballot_w64(c) | __builtin_amdgcn_ballot_w64(d);
+    return a | b | c | d;
 }
 
 // The sampled obstacle of one sample (reference utils.cu:144-157), in two steps: the first Box-Muller pair gives the
@@ -176,9 +179,28 @@ C2D_DEV void sample_obstacle(const Scene& sc, uint32_t radius_word, uint32_t ang
 #ifndef C2D_MC_EARLY_MASK
 #define C2D_MC_EARLY_MASK 0x2A  // bit i set: check after axis i+1 (axes 0-3 robot, 4-7 obstacle)
 #endif
-C2D_DEV bool sample_collides(const Scene& sc, const float (&o)[8])
+// The votes are kept as 64-bit lane masks built from ballots of the bare comparisons: a ballot of a comparison IS the
+// v_cmp's result, while a ballot of a boolean expression (ballot(!sep), ballot(hit && live)) makes the compiler rebuild
+// the boolean per lane first (v_cndmask 0/1 + v_cmp_ne), two VALU instructions per vote, four votes per evaluated sample.
+C2D_DEV unsigned long long wave_lanes() { return __builtin_amdgcn_ballot_w64(true); }  // the active lanes (exec)
+
+// lanes whose sample this axis separates (reference utils.cu:172-180: unfused dots, strict <), as a lane mask
+C2D_DEV unsigned long long axis_separates_mask(float ax, float ay, const float (&r1)[8], const float (&r2)[8])
 {
-    bool sep = false;
+    float p10 = dot2(ax, r1[0], ay, r1[1]), p11 = dot2(ax, r1[2], ay, r1[3]);
+    float p12 = dot2(ax, r1[4], ay, r1[5]), p13 = dot2(ax, r1[6], ay, r1[7]);
+    float p20 = dot2(ax, r2[0], ay, r2[1]), p21 = dot2(ax, r2[2], ay, r2[3]);
+    float p22 = dot2(ax, r2[4], ay, r2[5]), p23 = dot2(ax, r2[6], ay, r2[7]);
+    float min1 = min4(p10, p11, p12, p13), max1 = max4(p10, p11, p12, p13);
+    float min2 = min4(p20, p21, p22, p23), max2 = max4(p20, p21, p22, p23);
+    return __builtin_amdgcn_ballot_w64(max1 < min2) | __builtin_amdgcn_ballot_w64(max2 < min1);
+}
+
+// lanes whose sample collides (no axis separates it)
+C2D_DEV unsigned long long sample_collides_mask(const Scene& sc, const float (&o)[8])
+{
+    const unsigned long long lanes = wave_lanes();
+    unsigned long long sep = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         float ax, ay;
@@ -190,10 +212,10 @@ C2D_DEV bool sample_collides(const Scene& sc, const float (&o)[8])
             ax = o[(2 * j + 2) & 7] - o[2 * j];
             ay = o[(2 * j + 3) & 7] - o[2 * j + 1];
         }
-        sep |= axis_separates(ax, ay, sc.robot, o);
-        if (((C2D_MC_EARLY_MASK >> i) & 1) && __ballot(!sep) == 0ull) return false;
+        sep |= axis_separates_mask(ax, ay, sc.robot, o);
+        if (((C2D_MC_EARLY_MASK >> i) & 1) && (lanes & ~sep) == 0ull) return 0ull;
     }
-    return !sep;
+    return lanes & ~sep;
 }
 
 #ifndef C2D_MC_PRETEST_HOLDOFF
@@ -291,35 +313,42 @@ C2D_DEV uint32_t wave_count_hits_near(const Scene& sc, uint64_t seed, uint64_t s
             bool direct = false;  // evaluate this sub-iteration's samples straight from the registers
             float dx = 0.0f, dy = 0.0f;
             uint32_t w2r = 0, w2a = 0, sidx = 0;
-            bool live = false;
+            unsigned long long live_m = 0;  // lanes whose sample counts
             if (!flush) {
                 // ---- produce sub-iteration j: member j of the 64 groups
                 if (j == 2) have = false;
                 const uint32_t pos = 4 * lane + j;
                 const bool in_range = inner || (pos >= lo && pos < hi);
+                const unsigned long long in_m =
+                    inner ? wave_lanes() : (__builtin_amdgcn_ballot_w64(pos >= lo) & __builtin_amdgcn_ballot_w64(pos < hi));
                 const uint32_t rw = q.r[j][lane], aw = q.a[j][lane];
                 const bool odd = (j & 1) != 0;
                 sidx = sidx0 + j;
-                bool undecided = in_range;
+                bool undecided = in_range;           // per lane, for control flow ...
+                unsigned long long m = in_m;          // ... and the same vote as a lane mask
                 if (dense) {  // every lane needs the full evaluation anyway
                     dense--;
                     sample_centre(sc, rw, aw, dx, dy);
-                    live = in_range;
+                    live_m = in_m;
                     direct = true;
                 } else {
 #ifndef C2D_MC_NO_PRETEST
-                    undecided = in_range && !(sc.use_x0 && rw >= sc.x0);   // the radius word alone may prove the miss
-                    if (__ballot(undecided) == 0ull) continue;
+                    if (sc.use_x0) {  // the radius word alone may prove the miss
+                        const bool c = rw < sc.x0;
+                        undecided = undecided && c;
+                        m &= __builtin_amdgcn_ballot_w64(c);
+                    }
+                    if (m == 0ull) continue;
 #endif
                     sample_centre(sc, rw, aw, dx, dy);
 #ifndef C2D_MC_NO_PRETEST
-                    undecided = undecided && !centre_pretest(sc, dx, dy);
+                    unsigned long long miss_m;
+                    const bool miss = centre_pretest(sc, dx, dy, miss_m);  // (every lane votes: no short-circuit around it)
+                    undecided = undecided && !miss;
+                    m &= ~miss_m;
 #endif
-                }
-                const unsigned long long m = __ballot(undecided);
-                if (!direct) {
                     if (m == 0ull) continue;  // 64 certain misses
-                    if (m == ~0ull) dense = C2D_MC_PRETEST_HOLDOFF;
+                    if (m == wave_lanes()) dense = C2D_MC_PRETEST_HOLDOFF;
                 }
                 if (!have) {
                     const U4 pb = philox_draw_block(seed, scene_id, g, 2 + (j >> 1));
@@ -351,8 +380,8 @@ C2D_DEV uint32_t wave_count_hits_near(const Scene& sc, uint64_t seed, uint64_t s
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const uint32_t take = qn < 64 ? qn : 64;
-                live = lane < take;
-                const uint32_t src = qn - take + (live ? lane : 0);
+                live_m = take >= 64 ? ~0ull : (1ull << take) - 1;
+                const uint32_t src = qn - take + (lane < take ? lane : 0);
                 const float4 e = q.cw[src];
                 sidx = q.idx[src];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -366,7 +395,7 @@ C2D_DEV uint32_t wave_count_hits_near(const Scene& sc, uint64_t seed, uint64_t s
             }
             float o[8];
             sample_obstacle(sc, w2r, w2a, dx, dy, seed, scene_id, begin + sidx, o);
-            hits += (uint32_t)__popcll(__ballot(sample_collides(sc, o) && live));
+            hits += (uint32_t)__popcll(sample_collides_mask(sc, o) & live_m);
             if (flush) break;
         }
     }
@@ -394,10 +423,8 @@ C2D_DEV uint32_t wave_count_hits_far(const Scene& sc, uint64_t seed, uint64_t sc
     const uint32_t x0 = sc.x0;
     uint32_t gi = 0;
 
-    // one lane-private word of an iteration: queue it if it is a candidate
-    auto push_word = [&](uint32_t word, bool in_range, uint32_t sidx) {
-        const bool c = in_range && word < x0;
-        const unsigned long long m = __ballot(c);
+    // one lane-private word of an iteration: queue it if it is a candidate (m: the vote, a lane mask)
+    auto push_word = [&](uint32_t word, bool c, unsigned long long m, uint32_t sidx) {
         if (m == 0ull) return;
         if (c) {
             const uint32_t slot = cn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -406,17 +433,26 @@ C2D_DEV uint32_t wave_count_hits_far(const Scene& sc, uint64_t seed, uint64_t sc
         cn += (uint32_t)__popcll(m);
     };
     auto push_block = [&](const U4& r, uint32_t cgi) {
-        if (__ballot((r.x < x0) | (r.y < x0) | (r.z < x0) | (r.w < x0)) == 0ull) return;  // 256 certain misses
+        if (__builtin_amdgcn_ballot_w64((r.x < x0) | (r.y < x0) | (r.z < x0) | (r.w < x0)) == 0ull) return;  // 256 certain misses
         const uint32_t p0 = 4 * cgi;
         const uint32_t lo = p0 >= base ? 0u : base;
         const uint32_t rem = end_pos - p0;
         const uint32_t hi = rem < 256 ? rem : 256u;
         const uint32_t pos = 4 * lane;
         const uint32_t sidx = p0 - base + pos;
-        push_word(r.x, pos + 0 >= lo && pos + 0 < hi, sidx + 0);
-        push_word(r.y, pos + 1 >= lo && pos + 1 < hi, sidx + 1);
-        push_word(r.z, pos + 2 >= lo && pos + 2 < hi, sidx + 2);
-        push_word(r.w, pos + 3 >= lo && pos + 3 < hi, sidx + 3);
+        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+        const bool edge = lo != 0 || hi != 256;  // the first / last iteration of a range: some positions are not this call's
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            bool c = w[k] < x0;
+            unsigned long long m = __builtin_amdgcn_ballot_w64(c);  // votes of bare comparisons (see sample_collides_mask)
+            if (edge) {
+                const bool a = pos + k >= lo, b = pos + k < hi;
+                c = c && a && b;
+                m &= __builtin_amdgcn_ballot_w64(a) & __builtin_amdgcn_ballot_w64(b);
+            }
+            push_word(w[k], c, m, sidx + k);
+        }
     };
 
     for (;;) {
@@ -442,6 +478,7 @@ C2D_DEV uint32_t wave_count_hits_far(const Scene& sc, uint64_t seed, uint64_t sc
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const uint32_t take = cn < 64 ? cn : 64;
             const bool live = lane < take;
+            const unsigned long long live_m = take >= 64 ? ~0ull : (1ull << take) - 1;
             const uint2 e = q.cand[cn - take + (live ? lane : 0)];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -453,8 +490,10 @@ C2D_DEV uint32_t wave_count_hits_far(const Scene& sc, uint64_t seed, uint64_t sc
             const uint32_t aw = jj == 0 ? a.x : (jj == 1 ? a.y : (jj == 2 ? a.z : a.w));
             float dx, dy;
             sample_centre(sc, e.x, aw, dx, dy);
-            const bool undecided = live && !centre_pretest(sc, dx, dy);
-            const unsigned long long m = __ballot(undecided);
+            unsigned long long miss_m;
+            const bool miss = centre_pretest(sc, dx, dy, miss_m);  // (every lane votes: no short-circuit around it)
+            const bool undecided = live && !miss;
+            const unsigned long long m = live_m & ~miss_m;
             if (undecided) {
                 const uint32_t slot = un + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 q.und_c[slot] = make_float2(dx, dy);
@@ -468,8 +507,8 @@ C2D_DEV uint32_t wave_count_hits_far(const Scene& sc, uint64_t seed, uint64_t sc
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const uint32_t take = un < 64 ? un : 64;
-            const bool live = lane < take;
-            const uint32_t src = un - take + (live ? lane : 0);
+            const unsigned long long live_m = take >= 64 ? ~0ull : (1ull << take) - 1;
+            const uint32_t src = un - take + (lane < take ? lane : 0);
             const float2 c = q.und_c[src];
             const uint32_t sidx = q.und_idx[src];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -481,7 +520,7 @@ C2D_DEV uint32_t wave_count_hits_far(const Scene& sc, uint64_t seed, uint64_t sc
             const bool odd = (s & 1) != 0;
             float o[8];
             sample_obstacle(sc, odd ? pb.z : pb.x, odd ? pb.w : pb.y, c.x, c.y, seed, scene_id, s, o);
-            hits += (uint32_t)__popcll(__ballot(sample_collides(sc, o) && live));
+            hits += (uint32_t)__popcll(sample_collides_mask(sc, o) & live_m);
         }
         if (drained && cn == 0 && un == 0) break;
     }
