@@ -649,9 +649,10 @@ __global__ void mc_scenes_init_kernel(AdaptiveState* state, uint32_t n_scenes)
     *state = init;
 }
 
-// 6 waves per SIMD (80 VGPRs, two dwords spilled) instead of the 5 the compiler's 81 VGPRs allow: the certain-miss path is a
-// chain of dependent Philox multiplies, and the sixth wave is worth 5 % on the config-4 workload (806.7 -> 765.5 ms per
-// 4e6 data points) and 4 % on the reference-default batch; 8 waves (64 VGPRs, 17 dwords spilled) give nothing more.
+// 6 waves per SIMD (80 VGPRs; a dozen dwords spill, all but two reloads outside the sample loops) instead of the 5 the
+// compiler would take: the certain-miss path is a chain of dependent Philox multiplies, and the sixth wave is worth 3-5 % on
+// the config-4 workload (412 -> 400 ms per 4e6 data points with the group-of-four draw layout, 806.7 -> 765.5 ms before it)
+// and on the reference-default batch; 7 waves (72 VGPRs) give nothing more.
 #ifndef C2D_MC_ADV_WAVES
 #define C2D_MC_ADV_WAVES 6
 #endif
