@@ -67,6 +67,8 @@ def main():
         ok, info = one(eng, rng, i)
         fails += not ok
         total += info[-1]
+        if (i + 1) % 50 == 0:  # a sign of life for long runs
+            print(f"  {i + 1} / {configs} configurations, {fails} failures so far", flush=True)
     print(f"{configs} configurations, {fails} failures, {total:.3e} samples checked")
     sys.exit(1 if fails else 0)
 

@@ -65,6 +65,8 @@ def main():
         ok, info = one(eng, rng, i)
         fails += not ok
         rates.append(info[-1])
+        if (i + 1) % 50 == 0:  # a sign of life for long runs
+            print(f"  {i + 1} / {configs} configurations, {fails} failures so far", flush=True)
     print(f"{configs} configurations, {fails} failures; collide rate min {min(rates):.3f} median {np.median(rates):.3f} max {max(rates):.3f}")
     sys.exit(1 if fails else 0)
 
