@@ -11,7 +11,7 @@ SRCS := $(CSRC)/c2d_api.hip $(CSRC)/c2d_sat.hip $(CSRC)/c2d_poly.hip $(CSRC)/c2d
 OBJS := $(SRCS:.hip=.o)
 HDRS := $(CSRC)/c2d_math.hpp $(CSRC)/c2d_count.hpp $(CSRC)/c2d_internal.hpp include/c2d.h include/utils.h
 
-all: lib oracle drivers lib-fmad lib-nopretest
+all: lib oracle drivers lib-fmad lib-nopretest lib-rehearsal
 
 lib: $(LIBDIR)/libc2d.so
 
@@ -38,7 +38,7 @@ clean:
 	rm -f $(OBJS) $(LIBDIR)/libc2d.so $(BINDIR)/generate_dataset $(BINDIR)/compute_collision_probability $(BINDIR)/ztest
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle drivers tools clean lib-fmad lib-nopretest
+.PHONY: all lib oracle drivers tools clean lib-fmad lib-nopretest lib-rehearsal
 
 # developer tools (not shipped in libc2d.so)
 TOOLS := $(CSRC)/tools/sat_tune $(CSRC)/tools/pose_probe $(CSRC)/tools/clock_probe $(CSRC)/tools/instr_probe
@@ -60,3 +60,14 @@ $(LIBDIR)/libc2d_fmad%.so: $(SRCS) $(HDRS)
 	@mkdir -p $(LIBDIR) build/fmad$*
 	for f in $(SRCS); do $(HIPCC) $(HIPFLAGS) -DC2D_FMAD=$* -c $$f -o build/fmad$*/$$(basename $$f .hip).o || exit 1; done
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ build/fmad$*/*.o -ldl
+
+# rehearsal build (tests only): the same library with c2d_dist's file transport compiled in, under the product's file
+# name in its own directory, so that LD_LIBRARY_PATH / C2D_LIBRARY can put it in front of the product library for the
+# two-ranks-on-one-GPU tests (tests/test_gpu_dist.py).  The product libc2d.so contains no such transport.
+REHDIR := $(PKG)/lib-rehearsal
+lib-rehearsal: $(REHDIR)/libc2d.so
+$(CSRC)/c2d_dist_rehearsal.o: $(CSRC)/c2d_dist.hip $(HDRS)
+	$(HIPCC) $(HIPFLAGS) -DC2D_DIST_REHEARSAL -c $< -o $@
+$(REHDIR)/libc2d.so: $(OBJS) $(CSRC)/c2d_dist_rehearsal.o
+	@mkdir -p $(REHDIR)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(filter-out $(CSRC)/c2d_dist.o,$(OBJS)) $(CSRC)/c2d_dist_rehearsal.o -ldl

@@ -24,8 +24,14 @@ the children's status; launched under torch.distributed.run directly it is one o
 
 The reduce of each leg is the product's own: c2d_dist_all_reduce_sum_u64 of libc2d.so
 (ncclAllReduce of RCCL over xGMI, include/c2d.h); torch.distributed provides rendezvous,
-barriers and the max-over-ranks of the timings.  If the c2d communicator cannot be created the
-bench falls back to torch.distributed's all_reduce and says so in `config.reduce`.
+barriers and the max-over-ranks of the timings.  If the c2d communicator cannot be created, or
+RCCL counts another number of ranks than the launcher, every rank exits non-zero: a scaling
+curve of some other reduce is never reported (`--reduce torch` asks for torch's all_reduce
+explicitly).
+
+Parity in the same run (rank 0, N = 1): ALL booleans of the config-2 and config-5 batches are
+compared with the CPU oracle, and the first scenes of the config-4 shard with the oracle's
+adaptive loop (hits and sample counts); each of those legs carries its own `cpu_baseline`.
 """
 from __future__ import annotations
 
@@ -185,9 +191,11 @@ def main() -> None:
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
-            os.environ["C2D_DIST_TRANSPORT"] = "file"  # rehearsal: RCCL cannot put two ranks on one device
 
-    eng = pkg.Engine(local_rank)  # raises if libc2d.so is missing or the device is not gfx950
+    # --share-device is the rehearsal of the N > 1 code path on a box with fewer GPUs than ranks: RCCL cannot put two ranks
+    # on one device, so the ranks load the rehearsal build of the library (a sum through files; tests only, `make lib-rehearsal`)
+    lib_path = os.path.join(ROOT, "convex-2d-gpu-collision-detection_amd", "lib-rehearsal", "libc2d.so") if args.share_device else None
+    eng = pkg.Engine(local_rank, lib_path=lib_path)  # raises if libc2d.so is missing or the device is not gfx950
     stream = torch.cuda.Stream(device=dev)
     sh = stream.cuda_stream
     counts = measured_counts()
@@ -217,17 +225,21 @@ def main() -> None:
             ok = 0
             if any(uid):
                 try:
-                    cdist = eng.dist_init(rank, world, uid)
-                    ok = 1
+                    cdist = eng.dist_init(rank, world, uid)  # under libc2d's watchdog: C2D_ERR_DIST if a peer never arrives
+                    ok = 1 if cdist.world_size == world else 0
+                    if not ok:
+                        print(f"[bench] rank {rank}: RCCL counts {cdist.world_size} ranks in the communicator, the launcher {world}", file=sys.stderr)
                 except Exception as e:  # noqa: BLE001
-                    print(f"[bench] rank {rank}: c2d_dist_init failed ({e}); falling back to torch.distributed", file=sys.stderr)
+                    print(f"[bench] rank {rank}: c2d_dist_init failed ({e})", file=sys.stderr)
+            # every rank learns whether every rank succeeded, so that all of them leave together
             flag = torch.tensor([ok], dtype=torch.int32, device=dev if args.backend == "nccl" else None)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1:
-                reduce_impl = "libc2d c2d_dist_all_reduce_sum_u64 (%s, %d ranks in the communicator)" % (cdist.transport, cdist.world_size)
-            elif cdist is not None:
-                cdist.close()
-                cdist = None
+            if int(flag.item()) != 1:
+                print(f"[bench] rank {rank}: the product reduce (c2d_dist over RCCL) is not available on every rank; not measuring with "
+                      "another one (--reduce torch asks for torch.distributed explicitly)", file=sys.stderr)
+                dist.destroy_process_group()
+                os._exit(3)  # (a helper thread of the watchdog may still sit inside RCCL)
+            reduce_impl = "libc2d c2d_dist_all_reduce_sum_u64 (%s, %d ranks in the communicator)" % (cdist.transport, cdist.world_size)
 
     def all_reduce_sum(t):
         """The one collective of each leg: sum of 64-bit counters over ranks, in place (t: int64 device tensor)."""
@@ -446,7 +458,7 @@ def main() -> None:
                               "instr_source": c.get("source")}
 
     # ---- config 4: adaptive Monte-Carlo over many scenes -------------------------------------
-    scenes_leg = None
+    scenes_leg, scenes_keep = None, None
     if args.scenes > 0:
         ns = args.scenes
         tp, ts, _ = wl.random_tables(65536, 65536, seed=7)
@@ -454,30 +466,37 @@ def main() -> None:
         d_sc = eng.empty(ns, pkg.SCENE_DT)
         base = rank * ns  # scene ids (hence random streams) are global: rank r owns [r*ns, (r+1)*ns)
         eng.sample_scenes(d_p, 65536, d_s, 65536, 4.07, 1.74, 4.0, 7, base, ns, d_sc, stream=sh)
-        d_h, d_u = eng.zeros(ns, np.uint32, stream=sh), eng.zeros(ns, np.uint32, stream=sh)
-        eng.synchronize(sh)
+        # per-scene outputs as torch tensors (int32 holds the u32 counts: at most max_samples + one batch), so that the leg's
+        # totals are summed on the device, on the kernels' stream, without a host pass inside the timed region
+        t_h, t_u = torch.zeros(ns, dtype=torch.int32, device=dev), torch.zeros(ns, dtype=torch.int32, device=dev)
+        hsum = torch.zeros(2, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
         barrier()
         s0 = time.perf_counter()
         se0, se1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         se0.record(stream)
-        total, iters = eng.mc_scenes(d_p, 65536, d_s, 65536, d_sc, ns, 4.07, 1.74, wl.DEFAULT_BINS, wl.DEFAULT_BIN_ACCURACY,
-                                     args.scenes_max_samples, 11, base, d_h, d_u, None, stream=sh)
+        eng.mc_scenes_async(d_p, 65536, d_s, 65536, d_sc, ns, 4.07, 1.74, wl.DEFAULT_BINS, wl.DEFAULT_BIN_ACCURACY,
+                            args.scenes_max_samples, 11, base, t_h.data_ptr(), t_u.data_ptr(), None, stream=sh)
         se1.record(stream)
-        hsum = torch.zeros(2, dtype=torch.int64, device=dev)
-        hsum[0] = int(d_h.get().astype(np.int64).sum())
-        hsum[1] = total
-        local_total = total
+        with torch.cuda.stream(stream):
+            hsum[0] = t_h.sum(dtype=torch.int64)
+            hsum[1] = t_u.sum(dtype=torch.int64)
+            local_total = hsum[1].clone()
         all_reduce_sum(hsum)  # hit and sample totals: the one collective
         torch.cuda.synchronize()
         barrier()
         sel = shd.max_over_ranks(time.perf_counter() - s0, dev)
         loop_ms = se0.elapsed_time(se1)
-        scenes_leg = {"metric": "mc_samples_per_s", "value": float(hsum[1].item()) / sel, "data_points_per_gpu": ns,
-                      "max_samples": args.scenes_max_samples, "schedule_steps": iters, "seconds": round(sel, 4),
-                      "device_loop_ms": round(loop_ms, 3),
-                      "data_points_per_s": ns * world / sel, "mean_samples_per_point": float(hsum[1].item()) / (ns * world),
+        local_total = int(local_total.item())
+        steps_run = int(torch.unique(t_u).numel())  # distinct stop points seen (a lower bound of the schedule steps with work)
+        scenes_leg = {"metric": "mc_data_points_per_s", "value": ns * world / sel, "data_points_per_s": ns * world / sel,
+                      "data_points_per_gpu": ns, "max_samples": args.scenes_max_samples, "distinct_stop_points": steps_run,
+                      "seconds": round(sel, 4), "device_loop_ms": round(loop_ms, 3),
+                      "drawn_samples_per_s": float(hsum[1].item()) / sel, "mean_samples_per_point": float(hsum[1].item()) / (ns * world),
                       "pooled_hit_fraction": float(hsum[0].item()) / float(hsum[1].item()),
-                      "workload": "config4: scenes drawn by the generate_dataset formula from 65536-entry tables, adaptive stopping"}
+                      "workload": "config4: scenes drawn by the generate_dataset formula from 65536-entry tables, adaptive stopping",
+                      "note": "a data point = one (scene, obstacle instance) row of the dataset, sampled until its stop rule passes; "
+                              "drawn samples include those the kernels dismiss from their radius word alone (DESIGN.md §5)"}
         c = counts.get("mc_scenes.config4")
         if c and ns == c.get("data_points") and args.scenes_max_samples == c.get("max_samples"):
             lane = local_total / (loop_ms * 1e-3) * c["valu_instr_per_sample"] / 1e12
@@ -486,11 +505,19 @@ def main() -> None:
                                       "valu_instr_per_sample": c["valu_instr_per_sample"], "instr_source": c.get("source"),
                                       "note": "instructions per DRAWN sample: most samples of this workload are certain misses decided from "
                                               "their radius word, four words per Philox block (DESIGN.md §5); ~0 HBM bytes per sample"}
-        for a_ in (d_p, d_s, d_sc, d_h, d_u):
+            if c.get("evaluated_fraction"):
+                scenes_leg["evaluated_samples_per_s"] = float(hsum[1].item()) / sel * c["evaluated_fraction"]
+                scenes_leg["evaluated_fraction"] = c["evaluated_fraction"]
+                scenes_leg["evaluated_note"] = "samples that reach the full evaluation (second Box-Muller pair, vertices, SAT); recorded: %s" % c.get("evaluated_source")
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            scenes_keep = {"tables": (tp, ts), "scenes": d_sc.get(), "hits": t_h.cpu().numpy().view(np.uint32), "used": t_u.cpu().numpy().view(np.uint32),
+                           "base": base}
+        for a_ in (d_p, d_s, d_sc):
             a_.free()
+        del t_h, t_u
 
     # ---- config 5: convex polygons K <= 16 ---------------------------------------------------------
-    poly_leg = None
+    poly_leg, poly_keep = None, None
     if args.poly_pairs > 0:
         npoly = args.poly_pairs
         vx, vy, kk = torch_random_convex_polygons(torch, dev, npoly, seed=0xC0FFEE + rank)
@@ -541,6 +568,8 @@ def main() -> None:
             if c.get("hbm_bytes_per_launch"):
                 poly_leg["roofline"]["traffic"] = c["hbm_bytes_per_launch"]
                 poly_leg["roofline"]["traffic_source"] = "recorded, not measured in this run: %s" % c.get("source")
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            poly_keep = (vx.cpu().numpy(), vy.cpu().numpy(), kk.cpu().numpy(), pout.cpu().numpy())
         del vx, vy, kk
 
         # the same entry point on a tight layout of small polygons (triangles and quadrilaterals, 4 vertex rows: 67 B/pair)
@@ -571,46 +600,90 @@ def main() -> None:
             poly_leg["small_polygons"]["roofline"]["traffic_source"] = "recorded, not measured in this run: %s" % c4.get("source")
         del vx4, vy4, kk4, pout
 
-    # ---- CPU baseline: oracle port on this host, rank 0, N = 1 only ------------------------------
+    # ---- CPU baseline + full-size parity: oracle port on this host, rank 0, N = 1 only ------------------------------
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cpu as oracle  # checker / reported baseline only
 
         oracle.set_num_threads(oracle.usable_cores())  # the box's CPU share, not the host's thread count
+        budget = args.cpu_seconds
 
-        m = min(n, 2_000_000)
-        host_planes = planes[:, :m].contiguous().cpu().numpy()
-        gpu_out = out[:m].cpu().numpy()
-        ref, _ = oracle.sat_rect_pairs_verts(host_planes)  # warm-up + parity check of the sample
-        if not np.array_equal(ref, gpu_out):
-            raise SystemExit("PARITY FAILURE: GPU booleans differ from the CPU oracle on the bench sample")
+        # config 2: every boolean of the batch the timed steps produced
+        host_planes = planes.cpu().numpy()
+        gpu_out = out.cpu().numpy()
+        ref, ref_cnt = oracle.sat_rect_pairs_verts(host_planes)  # warm-up + parity check
+        equal = int((ref == gpu_out).sum())
+        parity = {"config2": f"booleans equal on {equal} of {n}"}
+        if equal != n or ref_cnt * args.steps != count_after_timed:
+            raise SystemExit(f"PARITY FAILURE: GPU booleans differ from the CPU oracle ({parity['config2']}; count {count_after_timed} vs {ref_cnt} x {args.steps})")
         reps, c0 = 0, time.perf_counter()
         while True:
             oracle.sat_rect_pairs_verts(host_planes)
             reps += 1
-            if time.perf_counter() - c0 >= args.cpu_seconds:
+            if time.perf_counter() - c0 >= budget:
                 break
         cel = time.perf_counter() - c0
-        cpu_baseline = {"value": m * reps / cel, "unit": "pair_tests/s", "cores": oracle.num_threads(), "kind": "port",
-                        "sample": f"first {m} pairs of the workload x {reps} passes ({cel:.1f} s), OpenMP, booleans checked equal to the GPU's"}
+        cpu_baseline = {"value": n * reps / cel, "unit": "pair_tests/s", "cores": oracle.num_threads(), "kind": "port",
+                        "sample": f"all {n} pairs of the workload x {reps} passes ({cel:.1f} s), OpenMP", "parity": parity["config2"]}
+        del host_planes
         if mc is not None:
             ms, done, h = 4_000_000, 0, 0
             c0 = time.perf_counter()
             while True:  # consecutive sample ranges of the same stream
                 h += oracle.mc_pair(sc["robot_w"], sc["robot_h"], sc["pos"], sc["pose"], sc["std_dev"], 1234, 0, done, ms)
                 done += ms
-                if time.perf_counter() - c0 >= args.cpu_seconds:
+                if time.perf_counter() - c0 >= budget:
                     break
             cel = time.perf_counter() - c0
             mc["cpu_baseline"] = {"value": done / cel, "unit": "samples/s", "cores": oracle.num_threads(), "kind": "port",
                                   "sample": f"first {done} samples of the same stream ({cel:.1f} s), OpenMP", "probability": h / done}
+        if poly_keep is not None:  # config 5: every boolean of the 16-row batch
+            hvx, hvy, hk, hout = poly_keep
+            ref, ref_cnt = oracle.sat_poly_pairs(hvx, hvy, hk)
+            equal = int((ref == hout).sum())
+            poly_leg["parity"] = f"booleans equal on {equal} of {len(ref)}"
+            if equal != len(ref):
+                raise SystemExit("PARITY FAILURE: GPU polygon booleans differ from the CPU oracle (%s)" % poly_leg["parity"])
+            reps, c0 = 0, time.perf_counter()
+            while True:
+                oracle.sat_poly_pairs(hvx, hvy, hk)
+                reps += 1
+                if time.perf_counter() - c0 >= budget:
+                    break
+            cel = time.perf_counter() - c0
+            poly_leg["cpu_baseline"] = {"value": len(ref) * reps / cel, "unit": "pair_tests/s", "cores": oracle.num_threads(), "kind": "port",
+                                        "sample": f"all {len(ref)} pairs of the workload x {reps} passes ({cel:.1f} s), OpenMP", "parity": poly_leg["parity"]}
+            poly_keep = None
+        if scenes_keep is not None:  # config 4: the oracle's adaptive loop on the first scenes of the shard, chunk by chunk
+            tp, ts = scenes_keep["tables"]
+            chunk, done, cpu_samples, bad = 2000, 0, 0, 0
+            c0 = time.perf_counter()
+            while done < len(scenes_keep["scenes"]):
+                m = min(chunk, len(scenes_keep["scenes"]) - done)
+                rh, ru, _, rt = oracle.mc_scenes(tp, ts, scenes_keep["scenes"][done:done + m], 4.07, 1.74, wl.DEFAULT_BINS, wl.DEFAULT_BIN_ACCURACY,
+                                                 args.scenes_max_samples, 11, scenes_keep["base"] + done)
+                bad += int((rh != scenes_keep["hits"][done:done + m]).sum()) + int((ru != scenes_keep["used"][done:done + m]).sum())
+                cpu_samples += rt
+                done += m
+                if time.perf_counter() - c0 >= budget:
+                    break
+            cel = time.perf_counter() - c0
+            scenes_leg["parity"] = (f"hits and sample counts equal on {done} of {done} data points checked" if not bad
+                                    else f"{bad} mismatching counts in the first {done} data points")
+            if bad:
+                raise SystemExit("PARITY FAILURE: adaptive Monte-Carlo results differ from the CPU oracle (%s)" % scenes_leg["parity"])
+            scenes_leg["cpu_baseline"] = {"value": done / cel, "unit": "data_points/s", "samples_per_s": cpu_samples / cel, "cores": oracle.num_threads(),
+                                          "kind": "port", "sample": f"first {done} data points of the shard ({cpu_samples} samples, {cel:.1f} s), OpenMP over scenes",
+                                          "parity": scenes_leg["parity"]}
+            scenes_keep = None
 
     if rank == 0:
         line = {
             "metric": "sat_pair_tests_per_s", "value": value, "unit": "pair_tests/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "config2: 1e7 random OBB pairs per GPU, 16 SoA vertex planes -> u8 booleans, single SAT overlap kernel",
+            "config": {"workload": ("config2: %s random OBB pairs per GPU, 16 SoA vertex planes -> u8 booleans, single SAT overlap kernel"
+                                    % ("1e7" if n == 10_000_000 else str(n))),
                        "pairs_per_gpu": n, "bytes_per_pair": BYTES_PER_PAIR, "collide_rate": round(collide_rate, 5),
                        "parallelism": f"pairs sharded over {world} GPU(s), one process per GPU, no data-path collective, one sum of the hit count per leg",
                        "reduce": reduce_impl,

@@ -233,6 +233,15 @@ C2D_DEV float min4(float a, float b, float c, float d) { return __builtin_fminf(
 C2D_DEV float max4(float a, float b, float c, float d) { return __builtin_fmaxf(__builtin_fmaxf(a, b), __builtin_fmaxf(c, d)); }
 
 // One SAT axis (reference utils.cu:172-180): unfused dots, strict <.
+//
+// Non-finite inputs.  thrust::minmax_element (utils.cu:176-177) is comparison based: both extremes start at element 0
+// and a later element replaces one only when `<` says so.  A NaN at k > 0 is therefore skipped — exactly what
+// v_min_f32 / v_max_f32 do — while a NaN at k = 0 stays to the end, makes both comparisons of :178 false and the axis
+// "not separating".  The min/max instructions below would drop that NaN too, so the one case is restored by one
+// unordered compare of the two first projections: with it the kernels follow the reference (and the oracle) for
+// every input bit pattern, infinities and NaNs included (tests/test_gpu_sat.py::test_non_finite_vertices).
+C2D_DEV bool first_projections_ordered(float p1_first, float p2_first) { return !__builtin_isunordered(p1_first, p2_first); }
+
 C2D_DEV bool axis_separates(float ax, float ay, const float (&r1)[8], const float (&r2)[8])
 {
     float p10 = dot2(ax, r1[0], ay, r1[1]), p11 = dot2(ax, r1[2], ay, r1[3]);
@@ -241,7 +250,7 @@ C2D_DEV bool axis_separates(float ax, float ay, const float (&r1)[8], const floa
     float p22 = dot2(ax, r2[4], ay, r2[5]), p23 = dot2(ax, r2[6], ay, r2[7]);
     float min1 = min4(p10, p11, p12, p13), max1 = max4(p10, p11, p12, p13);
     float min2 = min4(p20, p21, p22, p23), max2 = max4(p20, p21, p22, p23);
-    return (max1 < min2) || (max2 < min1);
+    return ((max1 < min2) || (max2 < min1)) && first_projections_ordered(p10, p20);
 }
 
 // convex_collide (reference utils.cu:159-184): 8 edge-vector axes, all evaluated.

@@ -41,6 +41,12 @@ struct Scene {
     // Radius-only form of the same pretest: raw word x >= x0 (and use_x0) proves a miss
     uint32_t x0;
     bool use_x0;
+    // use_x0 == false && x0 == 0 marks a scene that is not "tame": some parameter is NaN, infinite or >= 1e15 in
+    // magnitude, so a sampled vertex or a projection may be non-finite.  Such a scene takes wave_count_hits_plain: no
+    // pretest (their proofs assume numbers) and the axis test that restores minmax_element's behaviour on a NaN first
+    // projection (first_projections_ordered, c2d_math.hpp).  Below 1e15 no product on the way can overflow, so a tame
+    // scene never produces a NaN and pays for none of this (not even a register: the mark lives in x0).
+    C2D_DEV bool tame() const { return use_x0 || x0 != 0u; }
 };
 
 // |N(0,1) draw| of box_muller: the radius is at most sqrt(-2 ln 2^-33) = 6.7638 and
@@ -110,6 +116,16 @@ C2D_DEV Scene make_scene(float robot_w, float robot_h, float px, float py, const
     }
     sc.use_x0 = false;
     sc.x0 = 0xffffffffu;
+    {
+        const float big = 1e15f;  // (a NaN compares false: not tame)
+        auto ok = [big](float v) { return __builtin_fabsf(v) < big; };
+        const bool tame = ok(robot_w) && ok(robot_h) && ok(px) && ok(py) && ok(pose.width) && ok(pose.height) && ok(pose.theta) &&
+                          ok(sd.x) && ok(sd.y) && ok(sd.theta) && ok(sd.width) && ok(sd.height);
+        if (!tame) {
+            sc.x0 = 0u;  // the mark (see Scene::tame)
+            return sc;
+        }
+    }
     if (R0 > 0.25f && R0 < 1e30f) {  // below 0.25 fewer than 3 % of the draws would qualify anyway
         const float r = R0 * (1.0f - 0x1p-10f);
         const float u0 = __expf(-0.5f * r * r) * (1.0f + 0x1p-10f);  // fast exp: error 2^-21 relative, inside the slack
@@ -528,10 +544,33 @@ C2D_DEV uint32_t wave_count_hits_far(const Scene& sc, uint64_t seed, uint64_t sc
 }
 #endif
 
+// ---- PLAIN: a scene that is not tame (Scene::tame).  One sample per lane, every sample evaluated in full with the
+// axis test that is defined for every bit pattern (rect_collide, c2d_math.hpp); each lane draws its own blocks.  Slow
+// (four Philox blocks per sample) and rare by construction: tables of finite numbers never come here.
+C2D_DEV uint32_t wave_count_hits_plain(const Scene& sc, uint64_t seed, uint64_t scene_id, uint64_t begin, uint32_t count)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t hits = 0;
+#pragma nounroll
+    for (uint32_t i = 0; i < count; i += 64) {
+        const bool live = i + lane < count;
+        const uint64_t s = begin + i + lane;
+        const uint32_t j = (uint32_t)s & 3u;
+        const U4 b0 = philox_draw_block(seed, scene_id, s >> 2, 0), b1 = philox_draw_block(seed, scene_id, s >> 2, 1);
+        const U4 b2 = philox_draw_block(seed, scene_id, s >> 2, 2u + (j >> 1));
+        float dx, dy, o[8];
+        sample_centre(sc, u4_word(b0, (int)j), u4_word(b1, (int)j), dx, dy);
+        sample_obstacle(sc, (j & 1u) ? b2.z : b2.x, (j & 1u) ? b2.w : b2.y, dx, dy, seed, scene_id, s, o);
+        hits += (uint32_t)__popcll(__ballot(live && rect_collide(sc.robot, o)));
+    }
+    return hits;
+}
+
 // hits among samples [begin, begin + count) of one scene, computed by one wave
 C2D_DEV uint32_t wave_count_hits(const Scene& sc, uint64_t seed, uint64_t scene_id, uint64_t begin, uint32_t count,
                                  WaveQueue& q)
 {
+    if (!sc.tame()) return wave_count_hits_plain(sc, seed, scene_id, begin, count);
 #ifndef C2D_MC_NO_PRETEST  // validation builds evaluate every sample in full
     if (sc.use_x0 && sc.x0 < kFarX0) return wave_count_hits_far(sc, seed, scene_id, begin, count, q);
 #endif
@@ -1080,14 +1119,24 @@ int c2d_mc_scenes(c2d_ctx* ctx, const c2d_mc_scenes_args* a, c2d_stream stream)
         hipLaunchKernelGGL(mc_scenes_decide_kernel, dim3((unsigned)dec_blocks), dim3(256), 0, s, DB);
         it = burst;
     }
+    // Steps enqueued after the last scene finished retire at once (~5 us per launch pair).  A call that hands results to
+    // the host synchronises anyway, so on long schedules it looks at the state every kPollEvery steps and stops enqueuing
+    // once no scene is left; a call without host outputs stays asynchronous (graph-capturable) and enqueues all of them.
+    constexpr uint32_t kPollEvery = 64;
+    const bool host_out = a->total_samples || a->iterations;
+    AdaptiveState* h_state = reinterpret_cast<AdaptiveState*>(ctx->h_pinned);
     for (; it < steps; it++) {
         hipLaunchKernelGGL(mc_scenes_advance_kernel<false>, dim3((unsigned)adv_blocks), dim3(kMcBlock), 0, s, A);
         hipLaunchKernelGGL(mc_scenes_decide_kernel, dim3((unsigned)dec_blocks), dim3(256), 0, s, D);
+        if (host_out && (it + 1) % kPollEvery == 0 && it + 1 < steps) {
+            C2D_HIP(ctx, hipMemcpyAsync(h_state, d_state, sizeof(AdaptiveState), hipMemcpyDeviceToHost, s));
+            C2D_HIP(ctx, hipStreamSynchronize(s));
+            if (h_state->n_active == 0) break;
+        }
     }
     C2D_LAUNCH_CHECK(ctx);
     workspace_release(ctx, s, true);
-    if (a->total_samples || a->iterations) {  // host outputs requested: one read-back at the end
-        AdaptiveState* h_state = reinterpret_cast<AdaptiveState*>(ctx->h_pinned);
+    if (host_out) {  // host outputs requested: one read-back at the end
         C2D_HIP(ctx, hipMemcpyAsync(h_state, d_state, sizeof(AdaptiveState), hipMemcpyDeviceToHost, s));
         C2D_HIP(ctx, hipStreamSynchronize(s));
         if (a->total_samples) *a->total_samples = h_state->total_samples;

@@ -172,7 +172,9 @@ __global__ __launch_bounds__(64, MIN_WAVES) void sat_poly_kernel(const float* __
 #pragma unroll
         for (int r = 0; r < KM; r++)
             if (r < kmaxB) minmax_update(nx1, ny1, bx[r], by[r], mnB, mxB);
-        bool sep = (mxA < mnB) || (mxB < mnA);
+        // (a NaN first projection keeps an axis from separating, as the comparison-based extremes of utils.cu:176-178
+        // would: see first_projections_ordered in c2d_math.hpp)
+        bool sep = ((mxA < mnB) || (mxB < mnA)) && first_projections_ordered(nx1 * ax[0] + ny1 * ay[0], nx1 * bx[0] + ny1 * by[0]);
         sep = sep || bad;  // out-of-range vertex count: reported, result 0
         // ---- phase 2: full evaluation of the pairs that are still undecided -------------------------------
         // Up to kSlots undecided lanes park their vertices at once (the ds_write_b128 are issued once per group, not
@@ -238,7 +240,8 @@ __global__ __launch_bounds__(64, MIN_WAVES) void sat_poly_kernel(const float* __
                     minmax_update(nx, ny, q4.z, q4.w, mn2, mx2);
                     q4 = qn;
                 }
-                const unsigned long long bal = __ballot((mx1 < mn2) || (mx2 < mn1));
+                const float pa0 = nx * S[0].x + ny * S[0].y, pb0 = nx * S[KM].x + ny * S[KM].y;  // first projections (vertex 0 of A, of B)
+                const unsigned long long bal = __ballot(((mx1 < mn2) || (mx2 < mn1)) && first_projections_ordered(pa0, pb0));
                 constexpr unsigned long long kPairMask = LP == 64 ? ~0ull : ((1ull << LP) - 1ull);
 #pragma unroll
                 for (int q = 0; q < PP; q++) {
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(64) void sat_poly4_kernel(const float* __restrict__
                     minmax_update(nx, ny, px[r], py[r], mn1, mx1);
                     minmax_update(nx, ny, px[4 + r], py[4 + r], mn2, mx2);
                 }
-                sep |= (mx1 < mn2) || (mx2 < mn1);
+                sep |= ((mx1 < mn2) || (mx2 < mn1)) && first_projections_ordered(nx * px[0] + ny * py[0], nx * px[4] + ny * py[4]);
             }
             packed |= ((sep || bad) ? 0u : 1u) << (8 * e);
         }

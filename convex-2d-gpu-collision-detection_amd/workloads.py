@@ -82,3 +82,19 @@ def random_tables(num_poses: int, num_variances: int, seed: int = 7, shape_varia
     poses[:, 1] = rng.uniform(0.1, 5.0, num_poses)
     poses[:, 2] = rng.uniform(0.0, 2.0 * np.pi, num_poses)
     return poses.view(POSE_DT).reshape(-1), sd.view(STD_DT).reshape(-1), var
+
+
+def inject_non_finite(values: np.ndarray, seed: int, frac: float = 0.5, axis_items: int = -1) -> np.ndarray:
+    """Copy of `values` (float32 [planes][n], item index last) in which about `frac` of the items get one to three of
+    their coordinates replaced by NaN, +inf, -inf or +-3e38 (large enough for products to overflow).  Used by the tests
+    that pin the behaviour on non-finite vertices (include/c2d.h, "non-finite inputs")."""
+    rng = np.random.Generator(np.random.Philox(seed))
+    out = np.array(values, dtype=np.float32, copy=True)
+    flat = out.reshape(-1, out.shape[axis_items])
+    planes, n = flat.shape
+    junk = np.array([np.nan, np.inf, -np.inf, 3e38, -3e38], np.float32)
+    victims = np.flatnonzero(rng.random(n) < frac)
+    for rep in range(3):
+        sel = victims[rng.random(victims.size) < (1.0 if rep == 0 else 0.4)]
+        flat[rng.integers(0, planes, sel.size), sel] = rng.choice(junk, sel.size)
+    return out

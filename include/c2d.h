@@ -25,6 +25,18 @@
  * says fma; sin/cos/log are the c2d polynomial forms (bit-reproducible on any
  * IEEE machine), sqrt and divide are correctly rounded.  Booleans and hit
  * counts are therefore bit-exact against the CPU oracle in oracle/.
+ *
+ * Non-finite inputs.  The SAT entry points (c2d_sat_rect_pairs_*, c2d_sat_poly_pairs*,
+ * c2d_rects_from_poses) are defined for EVERY bit pattern and follow the reference there
+ * too: thrust::minmax_element (utils.cu:176-177) is comparison based, so on each axis a NaN
+ * projection of a polygon's FIRST vertex stays that polygon's extreme — both comparisons
+ * of utils.cu:178 are then false and the axis does not separate — while a NaN projection of
+ * a later vertex is skipped; infinities are ordered like numbers.  Consequence: a pair with
+ * a NaN in vertex 0 of either polygon reads "collide".  The Monte-Carlo entry points
+ * (c2d_mc_pair, c2d_mc_scenes, c2d_sample_scenes) take table-driven scene parameters and
+ * require them to be finite and below 1e15 in magnitude; outside that domain a call still
+ * terminates and stays memory-safe, and its hit counts follow the same rules (every
+ * certain-miss shortcut is switched off for such a scene).
  */
 #ifndef C2D_H_
 #define C2D_H_
@@ -254,7 +266,11 @@ int c2d_mc_pair(c2d_ctx* ctx, float robot_w, float robot_h, const Position* pos,
  * depend on batching, completion order or the number of GPUs.
  * The whole loop is enqueued on `stream` without any read-back (the schedule
  * state lives on the device); the call only synchronises when a host output
- * (total_samples, iterations) is requested. */
+ * (total_samples, iterations) is requested.  Every step of the schedule — until
+ * n_samples >= max_samples — is enqueued, 2 launches per step; steps after the last
+ * scene finished retire at once (~5 us).  Schedules of more than 100 000 steps are
+ * refused (C2D_ERR_INVALID_ARG): use larger batches.  With a host output requested the
+ * call looks at the device state every 64 steps and stops enqueuing once no scene is left. */
 typedef struct c2d_mc_scenes_args {
     const Pose* d_poses;          /* device Pose[num_poses]          (utils.cu:91-94)  */
     uint32_t num_poses;
@@ -316,9 +332,15 @@ int c2d_sample_scenes(c2d_ctx* ctx, const Pose* d_poses, uint32_t num_poses,
  *                        asynchronous on `stream` like every other entry point;
  *   c2d_dist_barrier   : a one-word all-reduce followed by a stream synchronise.
  *
- * C2D_DIST_TRANSPORT=file in the environment selects a rehearsal transport (host copies of
- * the counters summed through small files) that lets several ranks share one device, which
- * RCCL refuses; c2d_dist_transport() names the transport in use ("rccl" is the product path). */
+ * c2d_dist_init and c2d_dist_barrier (hence c2d_dist_init_file) run under a watchdog: if the
+ * peers do not arrive within the time limit (timeout_s of c2d_dist_init_file; $C2D_DIST_TIMEOUT_S
+ * or 300 s for c2d_dist_init) they return C2D_ERR_DIST instead of blocking for ever; the process
+ * should then report the error and end (a helper thread is left inside RCCL).
+ *
+ * c2d_dist_transport() names the transport: "rccl" — the only one this library contains.  A
+ * separate test build (lib-rehearsal/libc2d.so, `make lib-rehearsal`) replaces it by a sum
+ * through small files, which lets several ranks share one device (RCCL refuses that) so that
+ * the N > 1 host logic can be rehearsed on a one-GPU box; it reports "file (rehearsal)". */
 #define C2D_DIST_ID_BYTES 128
 typedef struct c2d_dist c2d_dist;
 int c2d_dist_unique_id(void* id_out /* [C2D_DIST_ID_BYTES] */);

@@ -55,6 +55,20 @@ def rot_trans_given_cs(r, dx, dy, c, s):
     return r
 
 
+def minmax_element(p):
+    """thrust::minmax_element over the last axis (utils.cu:176-177): comparison based — both extremes start at
+    element 0 and element k replaces one only when ``<`` says so, so a NaN at k > 0 is skipped and a NaN at
+    k = 0 stays (numpy's own min/max would propagate every NaN)."""
+    lo = p[..., 0].copy()
+    hi = p[..., 0].copy()
+    with np.errstate(invalid="ignore"):
+        for k in range(1, p.shape[-1]):
+            e = p[..., k]
+            lo = np.where(e < lo, e, lo)
+            hi = np.where(hi < e, e, hi)
+    return lo, hi
+
+
 def convex_collide(r1, r2):
     """utils.cu:159-184 for (n, 8) float32 arrays -> (n,) uint8.
 
@@ -66,17 +80,30 @@ def convex_collide(r1, r2):
     collide = np.ones(r1.shape[:-1], dtype=bool)
     for r in (r1, r2):
         for i in range(4):
-            n0 = r[..., (i + 1) * 2 % 8] - r[..., i * 2]
-            n1 = r[..., ((i + 1) * 2 + 1) % 8] - r[..., i * 2 + 1]
-            p1 = np.stack([n0 * r1[..., k * 2] + n1 * r1[..., k * 2 + 1] for k in range(4)], axis=-1)
-            p2 = np.stack([n0 * r2[..., k * 2] + n1 * r2[..., k * 2 + 1] for k in range(4)], axis=-1)
-            max1, min1 = p1.max(axis=-1), p1.min(axis=-1)
-            max2, min2 = p2.max(axis=-1), p2.min(axis=-1)
-            sep = (max1 < min2) | (max2 < min1)
+            with np.errstate(invalid="ignore", over="ignore"):
+                n0 = r[..., (i + 1) * 2 % 8] - r[..., i * 2]
+                n1 = r[..., ((i + 1) * 2 + 1) % 8] - r[..., i * 2 + 1]
+                p1 = np.stack([n0 * r1[..., k * 2] + n1 * r1[..., k * 2 + 1] for k in range(4)], axis=-1)
+                p2 = np.stack([n0 * r2[..., k * 2] + n1 * r2[..., k * 2 + 1] for k in range(4)], axis=-1)
+                min1, max1 = minmax_element(p1)
+                min2, max2 = minmax_element(p2)
+                sep = (max1 < min2) | (max2 < min1)
             collide &= ~sep
     return collide.astype(np.uint8)
 
 
+def _quiet(fn):
+    """numpy scalar arithmetic warns on overflow / invalid; non-finite inputs are part of the contract here."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **kw):
+        with np.errstate(all="ignore"):
+            return fn(*a, **kw)
+    return wrapped
+
+
+@_quiet
 def convex_collide_scalar(r1, r2):
     """Pure-Python loop form of utils.cu:159-184 for one pair (small cases)."""
     r1 = [F32(v) for v in r1]
@@ -88,11 +115,24 @@ def convex_collide_scalar(r1, r2):
             n1 = F32(r[((i + 1) * 2 + 1) % 8] - r[i * 2 + 1])
             p1 = [F32(F32(n0 * r1[k * 2]) + F32(n1 * r1[k * 2 + 1])) for k in range(4)]
             p2 = [F32(F32(n0 * r2[k * 2]) + F32(n1 * r2[k * 2 + 1])) for k in range(4)]
-            if max(p1) < min(p2) or max(p2) < min(p1):
+            (min1, max1), (min2, max2) = _minmax_scalar(p1), _minmax_scalar(p2)
+            if max1 < min2 or max2 < min1:
                 collide = 0
     return collide
 
 
+def _minmax_scalar(p):
+    """thrust::minmax_element for a list of scalars (see minmax_element)."""
+    lo = hi = p[0]
+    for e in p[1:]:
+        if e < lo:
+            lo = e
+        if hi < e:
+            hi = e
+    return lo, hi
+
+
+@_quiet
 def poly_collide(ax, ay, ka, bx, by, kb):
     """Convex polygon SAT with true normals (SURVEY.md F5) for one pair;
     ax/ay/bx/by are float32 sequences, ka/kb the vertex counts."""
@@ -107,7 +147,8 @@ def poly_collide(ax, ay, ka, bx, by, kb):
             nx, ny = F32(-ey), ex
             p1 = [F32(F32(nx * x) + F32(ny * y)) for x, y in A]
             p2 = [F32(F32(nx * x) + F32(ny * y)) for x, y in B]
-            if max(p1) < min(p2) or max(p2) < min(p1):
+            (min1, max1), (min2, max2) = _minmax_scalar(p1), _minmax_scalar(p2)
+            if max1 < min2 or max2 < min1:
                 collide = 0
     return collide
 
@@ -130,14 +171,21 @@ def poly_collide_batch(vx, vy, k):
                 break
             i1 = np.where(i + 1 < kp, i + 1, 0)
             cols = np.arange(n)
-            ex = vx[p][i1, cols] - vx[p][i]
-            ey = vy[p][i1, cols] - vy[p][i]
-            nx, ny = -ey, ex
             with np.errstate(invalid="ignore", over="ignore"):
+                ex = vx[p][i1, cols] - vx[p][i]
+                ey = vy[p][i1, cols] - vy[p][i]
+                nx, ny = -ey, ex
                 proj = [nx[None, :] * vx[q] + ny[None, :] * vy[q] for q in range(2)]
-            mn = [np.where(valid[q], proj[q], np.inf).min(axis=0) for q in range(2)]
-            mx = [np.where(valid[q], proj[q], -np.inf).max(axis=0) for q in range(2)]
-            sep = (mx[0] < mn[1]) | (mx[1] < mn[0])
+                mn, mx = [], []
+                for q in range(2):  # comparison-based extremes over the valid vertices, element 0 first (see minmax_element)
+                    lo, hi = proj[q][0].copy(), proj[q][0].copy()
+                    for r in range(1, KMAX):
+                        e = proj[q][r]
+                        lo = np.where(valid[q][r] & (e < lo), e, lo)
+                        hi = np.where(valid[q][r] & (hi < e), e, hi)
+                    mn.append(lo)
+                    mx.append(hi)
+                sep = (mx[0] < mn[1]) | (mx[1] < mn[0])
             collide &= ~(sep & has_edge)
     return collide.astype(np.uint8)
 

@@ -26,6 +26,7 @@ python3 profiles/pmc_digest.py $O/pmc_lds > profiles/${TAG}_pmc_lds.txt
 python3 convex-2d-gpu-collision-detection_amd/csrc/tools/scenes_trace.py digest $O/scenes_trace $O/scenes > profiles/${TAG}_scenes_trace.md
 cp $O/bench.json profiles/${TAG}_bench.json
 cp $O/bench_under_rocprof.json profiles/${TAG}_bench_under_rocprof.json
+python3 profiles/counts.py write $TAG   # measured_counts.json is generated from this tag's digests (tests/test_profiles.py verifies it)
 mkdir -p $R/gpurun_out/${TAG}_profiles && cp profiles/${TAG}_* $R/gpurun_out/${TAG}_profiles/
 # the raw traces are large: keep only what the digests came from, compressed
 find $O -name "*.csv" -size +2M -exec gzip -f {} \;

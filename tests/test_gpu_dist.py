@@ -4,8 +4,10 @@ What CAN run here and does:
   * c2d_dist with the real RCCL transport and a world of one rank (dlopen of librccl.so.1, ncclGetUniqueId,
     ncclCommInitRank, ncclAllReduce / ncclBroadcast on device words, the id-file exchange);
   * the N > 1 host logic of the C++ drivers and of bench.py with two ranks that SHARE device 0 and sum their
-    counters through the file rehearsal transport (C2D_DIST_TRANSPORT=file) — RCCL itself refuses two ranks on
+    counters through the rehearsal build of the library (lib-rehearsal/libc2d.so, put in front of the product
+    library with LD_LIBRARY_PATH / C2D_LIBRARY: a sum through small files) — RCCL itself refuses two ranks on
     one device ("Duplicate GPU detected"), so two-rank RCCL needs the multi-GPU node the round-end driver uses.
+    The product library has no such transport (checked below).
 The property under test everywhere: shards + one sum reproduce the single-process result exactly (random streams
 are keyed by scene id and sample index)."""
 import json
@@ -21,7 +23,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "convex-2d-gpu-collision-detection_amd", "bin")
 GEN = os.path.join(BIN, "generate_dataset")
 CCP = os.path.join(BIN, "compute_collision_probability")
-REHEARSAL = {"C2D_DIST_TRANSPORT": "file", "C2D_SHARE_DEVICE": "1"}
+LIB = os.path.join(ROOT, "convex-2d-gpu-collision-detection_amd", "lib", "libc2d.so")
+REH_DIR = os.path.join(ROOT, "convex-2d-gpu-collision-detection_amd", "lib-rehearsal")
+REH_LIB = os.path.join(REH_DIR, "libc2d.so")
+# the drivers find libc2d.so through their RUNPATH, which LD_LIBRARY_PATH precedes
+REHEARSAL = {"LD_LIBRARY_PATH": REH_DIR + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""), "C2D_SHARE_DEVICE": "1"}
 
 
 def run(cmd, env=None, **kw):
@@ -127,7 +133,7 @@ def test_ccp_two_ranks_equal_one_rank_both_launch_styles(tmp_path, wl):
     # (b) two processes started by hand (as a launcher would), id file given, NO --start_batch_count: rank 0's count is
     # broadcast, so the late starter cannot mis-number its files (racy start_batch_count)
     d3 = fresh_out("three")
-    env = dict(os.environ, C2D_DIST_TRANSPORT="file", WORLD_SIZE="2", LOCAL_RANK="0", C2D_DIST_ID_FILE=str(tmp_path / "idfile"))
+    env = dict(os.environ, WORLD_SIZE="2", LOCAL_RANK="0", C2D_DIST_ID_FILE=str(tmp_path / "idfile"), LD_LIBRARY_PATH=REHEARSAL["LD_LIBRARY_PATH"])
     p0 = subprocess.Popen([CCP, "--data_out", str(d3)] + common, env=dict(env, RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     p1 = subprocess.Popen([CCP, "--data_out", str(d3)] + common, env=dict(env, RANK="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     o0, e0 = p0.communicate(timeout=600)
@@ -180,7 +186,7 @@ def test_bench_starts_its_own_ranks(tmp_path):
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["config"]["ranks_in_reduce"] == 2 and "c2d_dist" in j["config"]["reduce"]
+    assert j["n_gpus"] == 2 and j["config"]["ranks_in_reduce"] == 2 and "c2d_dist" in j["config"]["reduce"] and "rehearsal" in j["config"]["reduce"]
     assert abs(j["mc"]["probability"] - 0.5537) < 5e-3 and j["poly"]["collide_rate"] > 0.03
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist"] + small, capture_output=True, text=True, timeout=900,
                          env=env)
@@ -205,17 +211,50 @@ def test_c2d_dist_error_paths(eng, pkg, tmp_path):
         eng.dist_init_file(0, 0, str(tmp_path / "x"), 1.0)
     with pytest.raises(ValueError):
         eng.dist_init(0, 1, b"short")
-    # the file transport named in an id made under C2D_DIST_TRANSPORT=file works with one rank too and reports itself
+    # the product library has one transport and no environment variable changes that
     os.environ["C2D_DIST_TRANSPORT"] = "file"
     try:
         d = eng.dist_init(0, 1, eng.dist_unique_id())
     finally:
         del os.environ["C2D_DIST_TRANSPORT"]
+    assert d.transport == "rccl"
+    d.close()
+
+
+def test_watchdog_times_out_instead_of_hanging(eng, pkg):
+    """A communicator whose second rank never arrives: ncclCommInitRank would block for ever; the watchdog returns
+    C2D_ERR_DIST after $C2D_DIST_TIMEOUT_S.  Run in a child process, because the helper thread stays inside RCCL."""
+    code = (
+        "import os, sys, time; sys.path.insert(0, %r)\n"
+        "os.environ['C2D_DIST_TIMEOUT_S'] = '4'\n"
+        "from __graft_entry__ import load_package; pkg = load_package(); eng = pkg.Engine(0)\n"
+        "t0 = time.time()\n"
+        "try:\n"
+        "    eng.dist_init(0, 2, eng.dist_unique_id())\n"
+        "    print('NO ERROR')\n"
+        "except pkg.C2DError as e:\n"
+        "    print('STATUS', e.status, round(time.time() - t0, 1), str(e))\n"
+        "sys.stdout.flush(); os._exit(0)\n" % ROOT)
+    out = run([sys.executable, "-c", code])
+    assert "STATUS -6" in out.stdout and "did not complete within 4 s" in out.stdout, out.stdout + out.stderr
+
+
+def test_rehearsal_transport_lives_in_its_own_build(eng, pkg):
+    """The file transport exists only in lib-rehearsal/libc2d.so: the product library holds none of its strings, and the
+    rehearsal build — same C-ABI — reports itself."""
+    prod, reh = open(LIB, "rb").read(), open(REH_LIB, "rb").read()
+    assert b"c2d-file-transport" not in prod and b"rehearsal" not in prod
+    assert b"c2d-file-transport" in reh
+    e2 = pkg.Engine(0, lib_path=REH_LIB)
+    d = e2.dist_init(0, 1, e2.dist_unique_id())
     assert d.transport == "file (rehearsal)" and d.world_size == 1
-    buf = eng.to_device(np.array([7, 9], np.uint64))
+    buf = e2.to_device(np.array([7, 9], np.uint64))
     d.all_reduce_sum_u64(buf, 2)
     d.broadcast_u64(buf, 2)
     d.barrier()
     assert buf.get().tolist() == [7, 9]
     d.close()
     buf.free()
+    with pytest.raises(pkg.C2DError):
+        e2.dist_init(0, 1, eng.dist_unique_id())   # an RCCL id is not a rehearsal id
+    e2.close()

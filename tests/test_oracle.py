@@ -296,3 +296,45 @@ def test_contraction_variants_of_the_oracle(oracle, wl):
         assert (pout != pref).sum() <= 2                                           # ... random pairs' booleans (almost) never
         h = v.mc_pair(sc["robot_w"], sc["robot_h"], sc["pos"], sc["pose"], sc["std_dev"], 1234, 0, 0, 1_000_000)
         assert abs(h - href) <= 5
+
+
+def test_non_finite_vertices_follow_minmax_element(oracle, wl):
+    """thrust::minmax_element (utils.cu:176-177) is comparison based: a NaN projection at element 0 stays the
+    extreme (the axis then never separates), a NaN at a later element is skipped.  Both restatements agree on
+    50 000 pairs with NaN / inf / overflowing coordinates, and on hand-made cases of each kind."""
+    poses = wl.random_obb_pose_planes(50_000, seed=1, extent=2.0)
+    planes = np.concatenate([oracle.rects_from_poses(*poses[:5]), oracle.rects_from_poses(*poses[5:])])
+    bad = wl.inject_non_finite(planes, seed=3)
+    assert np.isnan(bad).any() and np.isinf(bad).any()
+    got_c, _ = oracle.sat_rect_pairs_verts(bad)
+    got_np = sat.convex_collide(bad[:8].T, bad[8:].T)
+    assert np.array_equal(got_c, got_np)
+    for i in np.flatnonzero(~np.isfinite(bad).all(axis=0))[:40]:
+        assert sat.convex_collide_scalar(bad[:8, i], bad[8:, i]) == got_c[i]
+
+    def rect(cx, cy, w, h):
+        return np.array([cx - w / 2, cy - h / 2, cx + w / 2, cy - h / 2, cx + w / 2, cy + h / 2, cx - w / 2, cy + h / 2], np.float32)
+
+    a, far = rect(0, 0, 2, 2), rect(10, 0, 2, 2)
+    assert oracle.convex_collide(a, far) == 0
+    nan0 = far.copy()
+    nan0[0] = np.nan     # vertex 0 of rectangle 2: every axis sees a NaN first projection -> nothing separates
+    assert oracle.convex_collide(a, nan0) == 1 and sat.convex_collide_scalar(a, nan0) == 1
+    nan2 = far.copy()
+    nan2[4] = np.nan     # vertex 2: its projections are skipped; rectangle 1's own axes still separate the rest
+    assert oracle.convex_collide(a, nan2) == 0 and sat.convex_collide_scalar(a, nan2) == 0
+    inf1 = far.copy()
+    inf1[2] = np.inf     # an infinite vertex is ordered like any number
+    assert oracle.convex_collide(a, inf1) == sat.convex_collide_scalar(a, inf1)
+
+
+def test_non_finite_polygons_numpy_and_c_agree(oracle, wl):
+    vx, vy, k = wl.random_convex_polygons(20_000, seed=8, extent=2.0)
+    bx = wl.inject_non_finite(vx.reshape(32, -1), seed=4).reshape(vx.shape)
+    by = wl.inject_non_finite(vy.reshape(32, -1), seed=5, frac=0.2).reshape(vy.shape)
+    got_c, _ = oracle.sat_poly_pairs(bx, by, k)
+    got_np = sat.poly_collide_batch(bx, by, k)
+    assert np.array_equal(got_c, got_np)
+    touched = np.flatnonzero(~(np.isfinite(bx).all(axis=(0, 1)) & np.isfinite(by).all(axis=(0, 1))))
+    for i in touched[:25]:
+        assert sat.poly_collide(bx[0, :, i], by[0, :, i], int(k[0, i]), bx[1, :, i], by[1, :, i], int(k[1, i])) == got_c[i]

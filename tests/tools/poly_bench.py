@@ -13,7 +13,7 @@ import sys
 import torch  # before libc2d.so: one libamdhip64 per process
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package  # noqa: E402
 from bench import torch_random_convex_polygons  # noqa: E402
