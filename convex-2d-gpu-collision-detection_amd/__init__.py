@@ -13,6 +13,7 @@ from .binding import (  # noqa: F401
     C2DError,
     Engine,
     Dist,
+    PolyBins,
     DeviceArray,
     KMAX,
     POSE_DT,

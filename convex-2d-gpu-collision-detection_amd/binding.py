@@ -45,6 +45,12 @@ class _DeviceInfo(C.Structure):
                 ("wavefront_size", C.c_int), ("lds_bytes_per_cu", C.c_int), ("hbm_bytes", C.c_size_t)]
 
 
+class _PolyBin(C.Structure):
+    _fields_ = [("rows_a", C.c_uint32), ("rows_b", C.c_uint32), ("n", C.c_size_t), ("stride", C.c_size_t),
+                ("d_ax", C.c_void_p), ("d_ay", C.c_void_p), ("d_bx", C.c_void_p), ("d_by", C.c_void_p),
+                ("d_ka", C.c_void_p), ("d_kb", C.c_void_p), ("d_out", C.c_void_p)]
+
+
 class _McScenesArgs(C.Structure):
     _fields_ = [
         ("d_poses", C.c_void_p), ("num_poses", C.c_uint32),
@@ -94,6 +100,15 @@ _SIGNATURES = {
     "c2d_sat_rect_pairs_pose": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "c2d_sat_poly_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "c2d_sat_poly_pairs_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "c2d_poly_bins_create": (C.c_int, [C.c_void_p, C.POINTER(_PolyBin), C.c_size_t, C.POINTER(C.c_void_p)]),
+    "c2d_poly_bins_from_padded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p]),
+    "c2d_poly_bins_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "c2d_poly_bins_size": (C.c_size_t, [C.c_void_p]),
+    "c2d_poly_bins_pairs": (C.c_size_t, [C.c_void_p]),
+    "c2d_poly_bins_bytes": (C.c_size_t, [C.c_void_p]),
+    "c2d_poly_bins_get": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(_PolyBin)]),
+    "c2d_sat_poly_pairs_binned": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "c2d_poly_bins_results": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "c2d_philox_normals": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "c2d_math_eval": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "c2d_mc_pair": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.POINTER(_Position), C.POINTER(_Pose), C.POINTER(_StdDev),
@@ -198,6 +213,39 @@ class Dist:
     def close(self):
         if self.h:
             self.eng.lib.c2d_dist_destroy(self.h)
+            self.h = None
+
+
+class PolyBins:
+    """One c2d_poly_bins handle: the launch table of a binned polygon batch."""
+
+    def __init__(self, eng: "Engine", handle):
+        self.eng, self.h = eng, handle
+
+    def __len__(self) -> int:
+        return int(self.eng.lib.c2d_poly_bins_size(self.h))
+
+    @property
+    def pairs(self) -> int:
+        return int(self.eng.lib.c2d_poly_bins_pairs(self.h))
+
+    @property
+    def bytes(self) -> int:
+        return int(self.eng.lib.c2d_poly_bins_bytes(self.h))
+
+    def get(self, i: int) -> dict:
+        b = _PolyBin()
+        self.eng._check(self.eng.lib.c2d_poly_bins_get(self.h, i, C.byref(b)), "c2d_poly_bins_get")
+        return {"rows_a": b.rows_a, "rows_b": b.rows_b, "n": b.n, "stride": b.stride, "ax": b.d_ax or 0, "ay": b.d_ay or 0, "bx": b.d_bx or 0,
+                "by": b.d_by or 0, "ka": b.d_ka or 0, "kb": b.d_kb or 0, "out": b.d_out or 0}
+
+    def results(self, out, stream: int = 0):
+        """results in the order of the padded input (handles made by poly_bins_from_padded)"""
+        self.eng._check(self.eng.lib.c2d_poly_bins_results(self.eng.h, self.h, _ptr_of(out), C.c_void_p(stream)), "c2d_poly_bins_results")
+
+    def close(self):
+        if self.h:
+            self.eng.lib.c2d_poly_bins_destroy(self.eng.h, self.h)
             self.h = None
 
 
@@ -361,6 +409,30 @@ class Engine:
     def sat_poly_pairs(self, vx, vy, k, n: int, out, count=None, stream: int = 0):
         self._check(self.lib.c2d_sat_poly_pairs(self.h, _ptr_of(vx), _ptr_of(vy), _ptr_of(k), n, _ptr_of(out), _ptr_of(count),
                                                 C.c_void_p(stream)), "c2d_sat_poly_pairs")
+
+    # -- binned polygon batches (include/c2d.h "binned polygon batches") ---------------
+    def poly_bins_create(self, bins) -> "PolyBins":
+        """bins: sequence of dicts with rows_a, rows_b, n, ax, ay, bx, by, out and optionally ka, kb, stride
+        (device pointers or DeviceArrays)."""
+        arr = (_PolyBin * max(len(bins), 1))()
+        for i, b in enumerate(bins):
+            arr[i] = _PolyBin(b["rows_a"], b["rows_b"], b["n"], b.get("stride", 0), _ptr_of(b["ax"]), _ptr_of(b["ay"]), _ptr_of(b["bx"]),
+                              _ptr_of(b["by"]), _ptr_of(b.get("ka")), _ptr_of(b.get("kb")), _ptr_of(b["out"]))
+        h = C.c_void_p()
+        self._check(self.lib.c2d_poly_bins_create(self.h, arr, len(bins), C.byref(h)), "c2d_poly_bins_create")
+        return PolyBins(self, h)
+
+    def poly_bins_from_padded(self, vx, vy, k, n: int, rows: int, granularity: int, stream: int = 0) -> "PolyBins":
+        h = C.c_void_p()
+        st = self.lib.c2d_poly_bins_from_padded(self.h, _ptr_of(vx), _ptr_of(vy), _ptr_of(k), n, rows, granularity, C.byref(h), C.c_void_p(stream))
+        if st != 0:
+            if h.value:
+                self.lib.c2d_poly_bins_destroy(self.h, h)
+            self._check(st, "c2d_poly_bins_from_padded")
+        return PolyBins(self, h)
+
+    def sat_poly_pairs_binned(self, bins: "PolyBins", count=None, stream: int = 0):
+        self._check(self.lib.c2d_sat_poly_pairs_binned(self.h, bins.h, _ptr_of(count), C.c_void_p(stream)), "c2d_sat_poly_pairs_binned")
 
     # -- random stream / Monte-Carlo ------------------------------------------------
     def philox_normals(self, seed: int, scene_id: int, sample_begin: int, n: int, normals, raw=None, stream: int = 0):

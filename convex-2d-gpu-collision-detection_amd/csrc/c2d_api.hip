@@ -47,12 +47,14 @@ int c2d_ctx_create(int device, c2d_ctx** out)
     c2d::DeviceGuard g(device);
     if (!g.ok) { delete ctx; return C2D_ERR_NO_DEVICE; }
     if (hipMalloc(&ctx->d_counters, 64) != hipSuccess || hipMalloc(&ctx->d_count_words, C2D_COUNT_WORDS_BYTES) != hipSuccess ||
-        hipMemset(ctx->d_count_words, 0, C2D_COUNT_WORDS_BYTES) != hipSuccess || hipMalloc(&ctx->d_bins, 32 * sizeof(float)) != hipSuccess ||
+        hipMemset(ctx->d_count_words, 0, C2D_COUNT_WORDS_BYTES) != hipSuccess || hipMalloc(&ctx->d_count_words2, C2D_COUNT_WORDS2_BYTES) != hipSuccess ||
+        hipMemset(ctx->d_count_words2, 0, C2D_COUNT_WORDS2_BYTES) != hipSuccess || hipMalloc(&ctx->d_bins, 32 * sizeof(float)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pinned), 64, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&ctx->h_async_err), 64, hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->d_async_err), ctx->h_async_err, 0) != hipSuccess) {
         if (ctx->d_counters) (void)hipFree(ctx->d_counters);
         if (ctx->d_count_words) (void)hipFree(ctx->d_count_words);
+        if (ctx->d_count_words2) (void)hipFree(ctx->d_count_words2);
         if (ctx->d_bins) (void)hipFree(ctx->d_bins);
         if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
         if (ctx->h_async_err) (void)hipHostFree(ctx->h_async_err);
@@ -72,6 +74,7 @@ int c2d_ctx_destroy(c2d_ctx* ctx)
         if (p) (void)hipFree(p);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_count_words) (void)hipFree(ctx->d_count_words);
+    if (ctx->d_count_words2) (void)hipFree(ctx->d_count_words2);
     if (ctx->d_bins) (void)hipFree(ctx->d_bins);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->h_async_err) (void)hipHostFree(ctx->h_async_err);

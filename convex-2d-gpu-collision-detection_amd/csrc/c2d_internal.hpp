@@ -17,6 +17,7 @@ struct c2d_ctx {
     size_t list_capacity = 0;
     uint32_t* d_counters = nullptr;            // [0] next-active count
     unsigned long long* d_count_words = nullptr;  // 256 x 128 B arrival/sum words of the SAT count (self-clearing)
+    unsigned long long* d_count_words2 = nullptr; // two-level form for the polygon kernels (c2d_count.hpp), self-clearing
     float* d_bins = nullptr;                   // accuracy_bins | bin_accuracy (<= 32 floats)
     uint32_t* h_pinned = nullptr;              // pinned host word for count read-back
     // Deferred argument errors found by kernels (e.g. a polygon vertex count outside 1..KMAX): a pinned,
@@ -34,6 +35,7 @@ struct c2d_ctx {
 #define C2D_ASYNC_ERR_POLY_K 1u   /* polygon vertex count outside 1..C2D_POLY_KMAX */
 
 #define C2D_COUNT_WORDS_BYTES (256 * 128)
+#define C2D_COUNT_WORDS2_BYTES (2048 * 64 + 32 * 128)
 
 namespace c2d {
 

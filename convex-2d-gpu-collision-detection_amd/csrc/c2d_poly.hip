@@ -254,7 +254,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void sat_poly_kernel(const float* __
         if (in) out[p0 + lane] = collide ? (uint8_t)1 : (uint8_t)0;
         n_collide += (uint32_t)__popcll(__ballot(collide));
     }
-    if (d_count) wave_count_arrive_total(n_collide, d_count, words);
+    if (d_count) wave_count_arrive_total2(n_collide, d_count, words);  // one wave per 64 pairs: the two-level count
 }
 
 // ---- triangles and quadrilaterals in a 4-row layout: the rectangle kernel's shape ---------------------------------
@@ -345,17 +345,18 @@ int c2d_sat_poly_pairs_rows(c2d_ctx* ctx, const float* d_vx, const float* d_vy, 
     hipStream_t s = (hipStream_t)stream;
     if (int rc = workspace_acquire(ctx, s, d_count != nullptr)) return rc;
     uint32_t* err = ctx->d_async_err;
-    unsigned long long* words = ctx->d_count_words;
+    unsigned long long* words = ctx->d_count_words;     // sat_poly4_kernel: a wave per 256 pairs
+    unsigned long long* words2 = ctx->d_count_words2;   // sat_poly_kernel: a wave per 64 pairs (c2d_count.hpp)
     auto aligned = [](const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
     if (rows == 4 && n % 4 == 0 && aligned(d_vx, 16) && aligned(d_vy, 16) && aligned(d_k, 4) && aligned(d_out, 4)) {
         const size_t n_groups = n / 4;
         const size_t blocks = (n_groups + 63) / 64;
         hipLaunchKernelGGL(sat_poly4_kernel, dim3((unsigned)(blocks < (size_t)kMaxGrid ? blocks : (size_t)kMaxGrid)), dim3(64), 0, s, d_vx, d_vy, d_k, n,
                            n_groups, d_out, d_count, words, err);
-    } else if (rows == 16) launch_poly<16, 5, true>(s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words, err);
-    else if (rows > 8) launch_poly<16, 5, false>(s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words, err);
-    else if (rows > 4) launch_poly<8, 7, false>(s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words, err);
-    else launch_poly<4, 8, false>(s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words, err);
+    } else if (rows == 16) launch_poly<16, 5, true>(s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words2, err);
+    else if (rows > 8) launch_poly<16, 5, false>(s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words2, err);
+    else if (rows > 4) launch_poly<8, 7, false>(s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words2, err);
+    else launch_poly<4, 8, false>(s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words2, err);
     C2D_LAUNCH_CHECK(ctx);
     workspace_release(ctx, s, d_count != nullptr);
     return C2D_OK;

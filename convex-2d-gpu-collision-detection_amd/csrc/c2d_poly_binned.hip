@@ -1,0 +1,730 @@
+// c2d_poly_binned.hip — polygon SAT over BINNED batches (include/c2d.h, "binned polygon batches"; BASELINE config 5).
+//
+// Why bins.  In the padded layout f32[2][16][n] the pairs of a wave have unrelated vertex counts, so every 64-byte
+// segment of every vertex row holds a vertex somebody needs: 259 bytes move per pair for 155 bytes of real vertices
+// (K ~ U{3..16}), whatever the kernel does (sat_poly_kernel sits at the HBM ceiling on those 259 bytes).  A bin holds
+// pairs whose polygons have (about) the same size in a plane layout of its own: the bytes that move are the bytes that
+// are vertices, and the bin's row counts are known from the launch table — the vertex rows are requested at once,
+// without first waiting for the count bytes as sat_poly_kernel must (one memory round trip per tile instead of two).
+//
+// One launch covers every bin: block = one wave = one tile of 64 pairs of one bin; a u32 per tile names the bin, whose
+// descriptor arrives in scalar registers.  Arithmetic, phases and the early-out are those of sat_poly_kernel
+// (c2d_poly.hip): phase 1 tests ONE axis of polygon A per pair in registers — the edge whose normal points best at B —
+// phase 2 gives every undecided pair the full evaluation, lane = axis, vertices broadcast from LDS.  New here: the
+// lanes of phase 2 are dealt by the bin's axis count (rows_a + rows_b lanes per pair, as many pairs side by side as
+// fit the wave), not by a compile-time power of two.
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "c2d_internal.hpp"
+#include "c2d_math.hpp"
+#include "c2d_count.hpp"
+
+namespace c2d {
+
+constexpr int kBinSlots = 8;             // undecided pairs parked in LDS at once
+constexpr int kSlotF2 = 2 * C2D_POLY_KMAX + 2;  // float2 per slot: 32 vertices + 16 bytes, so that the slots start on different banks
+
+// launch-table entry (device memory, read through the scalar cache).  Polygon "A" of the table is the one with MORE
+// vertex rows (the host swaps the two polygons of a bin when rows_a < rows_b: SAT is symmetric and phase 1 draws its axis
+// from A), which also halves the number of phase-1 instances below.
+struct alignas(8) BinDesc {
+    const float* ax;
+    const float* ay;
+    const float* bx;
+    const float* by;
+    const uint8_t* ka;   // may be NULL: every polygon A of the bin has rows_a vertices
+    const uint8_t* kb;
+    uint8_t* out;
+    uint32_t n;          // pairs
+    uint32_t stride;     // elements between vertex rows
+    uint32_t tile0;      // first tile of the bin within the batch
+    uint16_t rows_a, rows_b;
+};
+static_assert(sizeof(BinDesc) == 72, "BinDesc layout");
+
+C2D_DEV void binned_minmax(float nx, float ny, float x, float y, float& mn, float& mx)
+{
+    const float p = nx * x + ny * y;  // unfused (translation unit is -ffp-contract=off), utils.cu:173
+    mn = __builtin_fminf(mn, p);
+    mx = __builtin_fmaxf(mx, p);
+}
+
+// One plane of a bin as a raw buffer: a row is addressed as (lane offset in a VGPR) + (row offset in ONE SGPR), so stepping to
+// the next row costs one scalar add for both coordinates (a flat 64-bit row pointer costs two per plane).  Planes are below
+// 4 GiB (checked when the table is built).
+C2D_DEV __amdgpu_buffer_rsrc_t plane_rsrc(const float* base, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
+}
+C2D_DEV float plane_load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 2 /* nt: streamed once */));
+}
+
+// ---- phase 1 of one tile, for bins with rows_a in (CA - 4, CA] and rows_b in (CB - 4, CB]: straight-line code over CA + CB
+// vertex slots.  Slots at and above a polygon's vertex count hold vertex 0, which is exactly neutral (a zero-length edge
+// never separates, a repeated projection changes no extreme), so only the LOADS of the last three rows are guarded.
+// Returns "separated by the one axis tested"; the vertices stay in ax .. by for the parking step of phase 2.
+template <int CA, int CB>
+C2D_DEV bool binned_phase1(const BinDesc& D, uint32_t p0, uint32_t cl, bool& bad, float (&ax)[C2D_POLY_KMAX], float (&ay)[C2D_POLY_KMAX],
+                           float (&bx)[C2D_POLY_KMAX], float (&by)[C2D_POLY_KMAX], uint32_t* __restrict__ async_err)
+{
+    const int rows_a = D.rows_a, rows_b = D.rows_b;
+    const uint32_t row_bytes = D.stride * 4u;
+    const uint32_t voff = cl * 4u;
+    {
+        const __amdgpu_buffer_rsrc_t rx = plane_rsrc(D.ax, (uint32_t)rows_a * row_bytes), ry = plane_rsrc(D.ay, (uint32_t)rows_a * row_bytes);
+        uint32_t soff = p0 * 4u;
+#pragma unroll
+        for (int r = 0; r < CA; r++) {
+            if (r <= CA - 4 || r < rows_a) {  // (rows_a > CA - 4: the first CA - 3 rows exist)
+                ax[r] = plane_load(rx, voff, soff);
+                ay[r] = plane_load(ry, voff, soff);
+            } else {
+                ax[r] = 0.0f;
+                ay[r] = 0.0f;
+            }
+            soff += row_bytes;
+        }
+    }
+    {
+        const __amdgpu_buffer_rsrc_t rx = plane_rsrc(D.bx, (uint32_t)rows_b * row_bytes), ry = plane_rsrc(D.by, (uint32_t)rows_b * row_bytes);
+        uint32_t soff = p0 * 4u;
+#pragma unroll
+        for (int r = 0; r < CB; r++) {
+            if (r <= CB - 4 || r < rows_b) {
+                bx[r] = plane_load(rx, voff, soff);
+                by[r] = plane_load(ry, voff, soff);
+            } else {
+                bx[r] = 0.0f;
+                by[r] = 0.0f;
+            }
+            soff += row_bytes;
+        }
+    }
+    int ka = rows_a, kb = rows_b;  // (per lane; wave-uniform in a bin without count arrays)
+    bad = false;
+    if (D.ka != nullptr) {
+        ka = D.ka[p0 + cl];
+        kb = D.kb[p0 + cl];
+        bad = ka < 1 || ka > rows_a || kb < 1 || kb > rows_b;
+        ka = ka < 1 ? 1 : (ka > rows_a ? rows_a : ka);
+        kb = kb < 1 ? 1 : (kb > rows_b ? rows_b : kb);
+        if (__ballot(bad) != 0 && threadIdx.x == 0) __hip_atomic_fetch_or(async_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // ---- neutral padding + vertex sums (for the direction between the vertex means)
+    float sax = ax[0], say = ay[0], sbx = bx[0], sby = by[0];
+#pragma unroll
+    for (int r = 1; r < CA; r++) {
+        const bool u = r < ka;
+        ax[r] = u ? ax[r] : ax[0];
+        ay[r] = u ? ay[r] : ay[0];
+        sax += ax[r];
+        say += ay[r];
+    }
+#pragma unroll
+    for (int r = 1; r < CB; r++) {
+        const bool u = r < kb;
+        bx[r] = u ? bx[r] : bx[0];
+        by[r] = u ? by[r] : by[0];
+        sbx += bx[r];
+        sby += by[r];
+    }
+    // mean of the real vertices: the sums hold (C - k) extra copies of vertex 0
+    const float ia = __builtin_amdgcn_rcpf((float)ka), ib = __builtin_amdgcn_rcpf((float)kb);
+    float dX = (sbx - (float)(CB - kb) * bx[0]) * ib - (sax - (float)(CA - ka) * ax[0]) * ia;
+    float dY = (sby - (float)(CB - kb) * by[0]) * ib - (say - (float)(CA - ka) * ay[0]) * ia;
+    {   // orientation of A: clockwise polygons have inward-pointing (-ey, ex), so the preferred direction flips
+        const float c = (ax[1] - ax[0]) * (ay[2] - ay[0]) - (ay[1] - ay[0]) * (ax[2] - ax[0]);
+        const uint32_t sgn = __float_as_uint(c) & 0x80000000u;
+        dX = __uint_as_float(__float_as_uint(dX) ^ sgn);
+        dY = __uint_as_float(__float_as_uint(dY) ^ sgn);
+    }
+    // ---- A's edge whose normal points best towards B: largest n.d / |n|, compared as t / l2 with t = (n.d) |n.d| and
+    // cross-multiplied (no reciprocal square root: a quarter-rate instruction per edge).  A heuristic in fast arithmetic —
+    // it only chooses WHICH canonical axis is evaluated; a zero-length edge gives 0 > -0 = false and is never chosen.
+    float bt = -1e30f, bl = 1.0f, nx1 = 0.0f, ny1 = 0.0f;
+#pragma unroll
+    for (int r = 0; r < CA; r++) {
+        const int r1 = (r + 1) % CA;    // (the slot after the last vertex holds vertex 0: the closing edge)
+        const float nx = -(ay[r1] - ay[r]);   // true normal (-ey, ex), exactly as phase 2 and the oracle
+        const float ny = ax[r1] - ax[r];
+        const float nd = fma_(nx, dX, ny * dY);
+        const float l2 = fma_(nx, nx, ny * ny);
+        const float t = nd * __builtin_fabsf(nd);
+        const bool better = t * bl > bt * l2;
+        bt = better ? t : bt;
+        bl = better ? l2 : bl;
+        nx1 = better ? nx : nx1;
+        ny1 = better ? ny : ny1;
+    }
+    float mnA = __builtin_inff(), mxA = -__builtin_inff(), mnB = __builtin_inff(), mxB = -__builtin_inff();
+#pragma unroll
+    for (int r = 0; r < CA; r++) binned_minmax(nx1, ny1, ax[r], ay[r], mnA, mxA);
+#pragma unroll
+    for (int r = 0; r < CB; r++) binned_minmax(nx1, ny1, bx[r], by[r], mnB, mxB);
+    // (a NaN first projection keeps an axis from separating: first_projections_ordered, c2d_math.hpp)
+    return ((mxA < mnB) || (mxB < mnA)) && first_projections_ordered(nx1 * ax[0] + ny1 * ay[0], nx1 * bx[0] + ny1 * by[0]);
+}
+
+// parking of one pair's vertices in an LDS slot: A's CA slots, then B's CB (both even), two vertices per ds_write_b128
+template <int CA, int CB>
+C2D_DEV void binned_park(float2* slot, const float (&ax)[C2D_POLY_KMAX], const float (&ay)[C2D_POLY_KMAX], const float (&bx)[C2D_POLY_KMAX],
+                         const float (&by)[C2D_POLY_KMAX])
+{
+    float4* S4 = reinterpret_cast<float4*>(slot);
+#pragma unroll
+    for (int r = 0; r < CA / 2; r++) S4[r] = make_float4(ax[2 * r], ay[2 * r], ax[2 * r + 1], ay[2 * r + 1]);
+#pragma unroll
+    for (int r = 0; r < CB / 2; r++) S4[CA / 2 + r] = make_float4(bx[2 * r], by[2 * r], bx[2 * r + 1], by[2 * r + 1]);
+}
+
+// the phase-1 / parking instance of a bin: rows rounded up to 4, 8, 12, 16 on either side, A the larger
+#define C2D_BIN_VARIANTS(X) X(4, 4) X(8, 4) X(8, 8) X(12, 4) X(12, 8) X(12, 12) X(16, 4) X(16, 8) X(16, 12) X(16, 16)
+C2D_DEV int bin_variant(int rows_a, int rows_b) { return ((rows_a + 3) >> 2) * 4 + ((rows_b + 3) >> 2); }   // ca4 * 4 + cb4, ca4 >= cb4 >= 1
+
+__global__ __launch_bounds__(64, 5) void sat_poly_binned_kernel(const BinDesc* __restrict__ bins, const uint32_t* __restrict__ tile_bin,
+                                                               uint32_t tile_offset, unsigned long long* __restrict__ d_count,
+                                                               unsigned long long* __restrict__ words, uint32_t* __restrict__ async_err)
+{
+    constexpr int KM = C2D_POLY_KMAX;
+    __shared__ __attribute__((aligned(16))) float2 s_slot[kBinSlots][kSlotF2];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t tile = blockIdx.x + tile_offset;
+    const uint32_t bin = __builtin_amdgcn_readfirstlane(tile_bin[tile]);
+    const BinDesc D = bins[bin];
+    const int rows_a = D.rows_a, rows_b = D.rows_b;
+    const uint32_t p0 = (tile - D.tile0) * 64u;
+    const uint32_t here = (D.n - p0) < 64u ? (D.n - p0) : 64u;  // wave-uniform
+    const bool in = lane < here;
+    const uint32_t cl = in ? lane : here - 1;  // lanes past the end re-read the last pair (never stored)
+    const int variant = bin_variant(rows_a, rows_b);
+    // ---- phase 1: one axis of A per pair, everything in registers ------------------------------------------------------
+    float ax[KM], ay[KM], bx[KM], by[KM];
+    bool sep = false, bad = false;
+    switch (variant) {
+#define C2D_BIN_CASE(CA, CB) case (CA / 4) * 4 + CB / 4: sep = binned_phase1<CA, CB>(D, p0, cl, bad, ax, ay, bx, by, async_err); break;
+        C2D_BIN_VARIANTS(C2D_BIN_CASE)
+#undef C2D_BIN_CASE
+    default: break;
+    }
+    sep = sep || bad;  // out-of-range vertex count: reported, result 0
+    // ---- phase 2: full evaluation of the pairs that are still undecided -------------------------------------------------
+    // Up to kBinSlots undecided lanes park their vertices in LDS; then PP pairs are evaluated side by side, LP = rows_a +
+    // rows_b lanes each: lane a of a pair's lanes owns axis a (A's edges first) and projects every vertex of both
+    // polygons, two per broadcast ds_read_b128; "some axis separates" is one slice of a ballot.
+    unsigned long long todo = __ballot(in && !sep);
+    if (todo) {
+        const int ca = ((rows_a + 3) >> 2) * 4;                        // float2 of A in a slot (B's follow)
+        const int ra2 = (rows_a + 1) >> 1, rb2 = (rows_b + 1) >> 1;   // vertex pairs (float4) of A / of B that hold real vertices
+        const int LP = rows_a + rows_b;
+        const int pp_fit = 64 / LP;
+        const int PP = pp_fit < kBinSlots ? pp_fit : kBinSlots;        // >= 2 because LP <= 32
+        uint32_t lane2 = lane;
+        asm volatile("" : "+v"(lane2));  // phase-2 lane roles are derived here, not hoisted into phase 1's register peak
+        const uint32_t magic = (65536u + (uint32_t)LP - 1u) / (uint32_t)LP;  // lane / LP for lane < 64 (exact: LP <= 32)
+        const int sub = (int)((lane2 * magic) >> 16);
+        const int a = (int)lane2 - sub * LP;
+        // the lane's edge: vertex indices within a slot (A at 0, B at ca)
+        const bool edge_of_a = a < rows_a;
+        const int eb = edge_of_a ? 0 : ca, ei = edge_of_a ? a : a - rows_a, en = edge_of_a ? rows_a : rows_b;
+        const int i0 = eb + ei, i1 = eb + (ei + 1 == en ? 0 : ei + 1);
+        const unsigned long long pair_mask = (1ull << LP) - 1ull;
+        while (todo) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u));
+            const bool park = ((todo >> lane) & 1ull) && rank < (uint32_t)kBinSlots;
+            __syncthreads();  // single-wave block: a wave-level fence (no s_barrier is emitted); earlier reads are done
+            if (park) {
+                float2* slot = &s_slot[rank][0];
+                switch (variant) {
+#define C2D_BIN_CASE(CA, CB) case (CA / 4) * 4 + CB / 4: binned_park<CA, CB>(slot, ax, ay, bx, by); break;
+                    C2D_BIN_VARIANTS(C2D_BIN_CASE)
+#undef C2D_BIN_CASE
+                default: break;
+                }
+            }
+            __syncthreads();
+            const int left = __popcll(todo);
+            const int g = left < kBinSlots ? left : kBinSlots;
+            for (int i = 0; i < g; i += PP) {
+                const int cnt = (g - i) < PP ? (g - i) : PP;  // pairs of this trip (wave-uniform)
+                const float2* S = &s_slot[i + (sub < cnt ? sub : 0)][0];  // lanes without a pair of their own repeat the first
+                const float4* SA = reinterpret_cast<const float4*>(S);
+                const float4* SB = reinterpret_cast<const float4*>(S + ca);
+                const float2 e0 = S[i0], e1 = S[i1];
+                const float nx = -(e1.y - e0.y), ny = e1.x - e0.x;
+                float mn1 = __builtin_inff(), mx1 = -__builtin_inff(), mn2 = __builtin_inff(), mx2 = -__builtin_inff();
+                // slots past a polygon's count repeat its vertex 0, so the scans need no masking
+                for (int r2 = 0; r2 < ra2; r2++) {
+                    const float4 q4 = SA[r2];
+                    binned_minmax(nx, ny, q4.x, q4.y, mn1, mx1);
+                    binned_minmax(nx, ny, q4.z, q4.w, mn1, mx1);
+                }
+                for (int r2 = 0; r2 < rb2; r2++) {
+                    const float4 q4 = SB[r2];
+                    binned_minmax(nx, ny, q4.x, q4.y, mn2, mx2);
+                    binned_minmax(nx, ny, q4.z, q4.w, mn2, mx2);
+                }
+                const float pa0 = nx * S[0].x + ny * S[0].y, pb0 = nx * S[ca].x + ny * S[ca].y;  // first projections
+                const unsigned long long bal = (__builtin_amdgcn_ballot_w64(mx1 < mn2) | __builtin_amdgcn_ballot_w64(mx2 < mn1)) &
+                                               __builtin_amdgcn_ballot_w64(first_projections_ordered(pa0, pb0));
+                for (int q = 0; q < cnt; q++) {
+                    const int j = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    const bool any = ((bal >> (q * LP)) & pair_mask) != 0ull;
+                    sep = ((int)lane == j) ? any : sep;
+                }
+            }
+        }
+    }
+    const bool collide = in && !sep;
+    if (in) D.out[p0 + lane] = collide ? (uint8_t)1 : (uint8_t)0;
+    if (d_count) wave_count_arrive_total2((uint32_t)__popcll(__ballot(collide)), d_count, words);
+}
+static_assert(kCountWords2Bytes == C2D_COUNT_WORDS2_BYTES, "workspace size of the two-level count");
+
+// ---- binning a padded batch -------------------------------------------------------------------------------------------
+// class of a pair: (ceil(ka / g) - 1) * 16 + (ceil(kb / g) - 1); counts outside 1..rows go to class 255 = "bad" which is
+// reported and whose pairs read 0
+C2D_DEV uint32_t bin_class(int ka, int kb, int rows, int g)
+{
+    if (ka < 1 || ka > rows || kb < 1 || kb > rows) return 0xffffffffu;
+    return (uint32_t)(((ka + g - 1) / g - 1) * 16 + ((kb + g - 1) / g - 1));
+}
+
+// Binning is a stable counting sort by class in three passes, so that every bin keeps its pairs in input order and the
+// result does not depend on scheduling:
+//   count  a block takes 1024 consecutive pairs; every wave ranks its lanes within their class (ballot per distinct class)
+//          and the block writes its 256 class counts;
+//   scan   one block per class turns the column of block counts into exclusive prefixes (+ the class total for the host);
+//   move   the same ranking again gives slot = prefix[block][class] + pairs of the class in earlier waves + rank in the
+//          wave; every lane copies its own pair: coalesced reads of the padded rows, 4-byte writes that neighbouring
+//          lanes / waves / blocks of a class put next to each other.
+constexpr int kBinBlock = 1024, kBinWaves = kBinBlock / 64;
+
+// rank of the lane among the wave's lanes of its class (lanes with ok == false take no part); s_wc[class] gets the wave's count
+C2D_DEV uint32_t wave_class_rank(uint32_t c, bool ok, uint16_t* s_wc)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t rank = 0;
+    unsigned long long rest = __ballot(ok);
+    while (rest) {
+        const int first = __ffsll((long long)rest) - 1;
+        const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)c, first);
+        const unsigned long long m = __ballot(ok && c == c0);
+        if (ok && c == c0) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if ((int)lane == first) s_wc[c0] = (uint16_t)__popcll(m);
+        rest &= ~m;
+    }
+    return rank;
+}
+
+__global__ __launch_bounds__(kBinBlock) void poly_bin_count_kernel(const uint8_t* __restrict__ k, size_t n, int rows, int g,
+                                                                    uint32_t* __restrict__ block_hist, uint32_t* __restrict__ n_bad)
+{
+    __shared__ uint16_t s_wc[kBinWaves][256];
+    for (int i = threadIdx.x; i < kBinWaves * 256; i += kBinBlock) (&s_wc[0][0])[i] = 0;
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * kBinBlock + threadIdx.x;
+    uint32_t c = 0xffffffffu;
+    if (i < n) c = bin_class(k[i], k[n + i], rows, g);
+    const bool ok = c != 0xffffffffu;
+    if (__ballot(i < n && !ok) != 0 && (threadIdx.x & 63) == 0) atomicAdd(n_bad, 1u);
+    (void)wave_class_rank(c, ok, s_wc[threadIdx.x >> 6]);
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < kBinWaves; w++) t += s_wc[w][threadIdx.x];
+        block_hist[(size_t)blockIdx.x * 256 + threadIdx.x] = t;
+    }
+}
+
+// exclusive prefix over the blocks, one class per block; totals[c] = pairs of the class
+__global__ __launch_bounds__(256) void poly_bin_scan_kernel(uint32_t* __restrict__ block_hist, uint32_t n_blocks, uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t s_part[256];
+    const uint32_t c = blockIdx.x, t = threadIdx.x;
+    const uint32_t per = (n_blocks + 255) / 256;
+    const uint32_t b0 = t * per, b1 = (b0 + per) < n_blocks ? (b0 + per) : n_blocks;
+    uint32_t sum = 0;
+    for (uint32_t b = b0; b < b1; b++) sum += block_hist[(size_t)b * 256 + c];
+    s_part[t] = sum;
+    __syncthreads();
+    if (t == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < 256; i++) { const uint32_t v = s_part[i]; s_part[i] = run; run += v; }
+        totals[c] = run;
+    }
+    __syncthreads();
+    uint32_t run = s_part[t];
+    for (uint32_t b = b0; b < b1; b++) {
+        const uint32_t v = block_hist[(size_t)b * 256 + c];
+        block_hist[(size_t)b * 256 + c] = run;
+        run += v;
+    }
+}
+
+struct BinMoveArgs {
+    const float* vx;
+    const float* vy;
+    const uint8_t* k;
+    size_t n;
+    int rows, g;
+    const BinDesc* table;          // one entry per bin, polygons as in the INPUT (not the test kernel's swapped view)
+    const uint16_t* class_to_bin;  // [256], 0xffff = empty class
+    const uint32_t* pair_base;     // [bins]: first position of the bin in the concatenated order
+    const uint32_t* block_prefix;  // [blocks][256] from the scan
+    uint32_t* index;               // [n] out: position of input pair i; 0xffffffff = bad counts
+};
+
+__global__ __launch_bounds__(kBinBlock) void poly_bin_move_kernel(BinMoveArgs A)
+{
+    __shared__ uint16_t s_wc[kBinWaves][256];
+    for (int i = threadIdx.x; i < kBinWaves * 256; i += kBinBlock) (&s_wc[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * kBinBlock + threadIdx.x;
+    const bool in = i < A.n;
+    int ka = 0, kb = 0;
+    uint32_t c = 0xffffffffu;
+    if (in) {
+        ka = A.k[i];
+        kb = A.k[A.n + i];
+        c = bin_class(ka, kb, A.rows, A.g);
+    }
+    const bool ok = c != 0xffffffffu;
+    const uint32_t rank = wave_class_rank(c, ok, s_wc[wave]);
+    __syncthreads();
+    if (in) A.index[i] = 0xffffffffu;
+    if (!ok) return;
+    uint32_t before = 0;  // pairs of the class in earlier waves of the block
+    for (uint32_t w = 0; w < wave; w++) before += s_wc[w][c];
+    const uint32_t slot = A.block_prefix[(size_t)blockIdx.x * 256 + c] + before + rank;
+    const uint32_t bin = A.class_to_bin[c];
+    A.index[i] = A.pair_base[bin] + slot;
+    const BinDesc D = A.table[bin];
+    const int ra = D.rows_a, rb = D.rows_b;
+    const size_t n = A.n;
+    for (int r = 0; r < ra; r++) {
+        const_cast<float*>(D.ax)[(size_t)r * D.stride + slot] = A.vx[(size_t)r * n + i];
+        const_cast<float*>(D.ay)[(size_t)r * D.stride + slot] = A.vy[(size_t)r * n + i];
+    }
+    for (int r = 0; r < rb; r++) {
+        const_cast<float*>(D.bx)[(size_t)r * D.stride + slot] = A.vx[((size_t)A.rows + r) * n + i];
+        const_cast<float*>(D.by)[(size_t)r * D.stride + slot] = A.vy[((size_t)A.rows + r) * n + i];
+    }
+    if (D.ka) {
+        const_cast<uint8_t*>(D.ka)[slot] = (uint8_t)ka;
+        const_cast<uint8_t*>(D.kb)[slot] = (uint8_t)kb;
+    }
+}
+
+__global__ __launch_bounds__(256) void poly_bins_results_kernel(const uint8_t* __restrict__ out_all, const uint32_t* __restrict__ index, size_t n,
+                                                               uint8_t* __restrict__ out)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const uint32_t p = index[i];
+        out[i] = p == 0xffffffffu ? (uint8_t)0 : out_all[p];
+    }
+}
+
+}  // namespace c2d
+
+using namespace c2d;
+
+struct c2d_poly_bins {
+    int device = 0;
+    std::vector<c2d_poly_bin> bins;   // as given (strides resolved)
+    std::vector<uint32_t> strides;
+    BinDesc* d_table = nullptr;
+    uint32_t* d_tile_bin = nullptr;
+    size_t n_tiles = 0, pairs = 0, bytes = 0;
+    // handles made by c2d_poly_bins_from_padded own their data
+    void* d_block = nullptr;
+    uint8_t* d_out_all = nullptr;     // inside d_block: every bin's results, in bin order
+    uint32_t* d_index = nullptr;      // inside d_block
+    size_t n_input = 0;
+    bool had_bad_counts = false;
+};
+
+namespace {
+
+// the launch table as the test kernel wants it: polygon A of an entry is the one with more rows
+int upload_table(c2d_ctx* ctx, c2d_poly_bins* B)
+{
+    std::vector<BinDesc> table(B->bins.size());
+    std::vector<uint32_t> tile_bin;
+    size_t tiles = 0;
+    B->pairs = 0;
+    B->bytes = 0;
+    for (size_t b = 0; b < B->bins.size(); b++) {
+        const c2d_poly_bin& s = B->bins[b];
+        BinDesc& d = table[b];
+        d.ax = s.d_ax; d.ay = s.d_ay; d.bx = s.d_bx; d.by = s.d_by; d.ka = s.d_ka; d.kb = s.d_kb; d.out = s.d_out;
+        d.n = (uint32_t)s.n;
+        d.stride = B->strides[b];
+        d.tile0 = (uint32_t)tiles;
+        d.rows_a = (uint16_t)s.rows_a;
+        d.rows_b = (uint16_t)s.rows_b;
+        if (d.rows_a < d.rows_b) {  // SAT is symmetric: the kernel takes its phase-1 axis from the polygon with more edges
+            std::swap(d.ax, d.bx);
+            std::swap(d.ay, d.by);
+            std::swap(d.ka, d.kb);
+            std::swap(d.rows_a, d.rows_b);
+        }
+        if ((uint64_t)d.rows_a * d.stride * 4 > 0xffffffffull) return fail_arg(ctx, "c2d_poly_bins: a vertex plane of a bin exceeds 4 GiB (split the bin)");
+        const size_t t = (s.n + 63) / 64;
+        tiles += t;
+        if (tiles > 0xffffffffull) return fail_arg(ctx, "c2d_poly_bins: more than 2^32 tiles in one batch");
+        tile_bin.insert(tile_bin.end(), t, (uint32_t)b);
+        B->pairs += s.n;
+        B->bytes += s.n * ((size_t)(s.rows_a + s.rows_b) * 8 + (s.d_ka ? 2 : 0) + 1);
+    }
+    B->n_tiles = tiles;
+    if (!table.empty()) {
+        C2D_HIP(ctx, hipMalloc(&B->d_table, table.size() * sizeof(BinDesc)));
+        C2D_HIP(ctx, hipMemcpy(B->d_table, table.data(), table.size() * sizeof(BinDesc), hipMemcpyHostToDevice));
+    }
+    if (tiles) {
+        C2D_HIP(ctx, hipMalloc(&B->d_tile_bin, tiles * sizeof(uint32_t)));
+        C2D_HIP(ctx, hipMemcpy(B->d_tile_bin, tile_bin.data(), tiles * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    return C2D_OK;
+}
+
+void release(c2d_poly_bins* B)
+{
+    if (!B) return;
+    if (B->d_table) (void)hipFree(B->d_table);
+    if (B->d_tile_bin) (void)hipFree(B->d_tile_bin);
+    if (B->d_block) (void)hipFree(B->d_block);
+    delete B;
+}
+
+}  // namespace
+
+extern "C" {
+
+int c2d_poly_bins_create(c2d_ctx* ctx, const c2d_poly_bin* bins, size_t n_bins, c2d_poly_bins** out)
+{
+    if (!ctx || !out) return C2D_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (n_bins && !bins) return fail_arg(ctx, "c2d_poly_bins_create: NULL bins");
+    if (n_bins > 65535) return fail_arg(ctx, "c2d_poly_bins_create: more than 65535 bins");
+    c2d_poly_bins* B = new (std::nothrow) c2d_poly_bins();
+    if (!B) return C2D_ERR_NOMEM;
+    B->device = ctx->device;
+    for (size_t b = 0; b < n_bins; b++) {
+        const c2d_poly_bin& s = bins[b];
+        const char* why = nullptr;
+        if (s.rows_a < 1 || s.rows_a > C2D_POLY_KMAX || s.rows_b < 1 || s.rows_b > C2D_POLY_KMAX) why = "c2d_poly_bins_create: rows_a / rows_b must be 1..C2D_POLY_KMAX";
+        else if (s.n > 0xffffffffull) why = "c2d_poly_bins_create: a bin holds at most 2^32 - 1 pairs";
+        else if (s.stride != 0 && s.stride < s.n) why = "c2d_poly_bins_create: stride must be 0 or >= n";
+        else if (s.stride > 0xffffffffull) why = "c2d_poly_bins_create: stride must fit 32 bits";
+        else if (s.n && (!s.d_ax || !s.d_ay || !s.d_bx || !s.d_by || !s.d_out)) why = "c2d_poly_bins_create: NULL plane or result pointer";
+        else if ((s.d_ka == nullptr) != (s.d_kb == nullptr)) why = "c2d_poly_bins_create: d_ka and d_kb must both be given or both be NULL";
+        if (why) { release(B); return fail_arg(ctx, why); }
+        if (s.n == 0) continue;  // empty bins take no tiles
+        B->bins.push_back(s);
+        B->strides.push_back((uint32_t)(s.stride ? s.stride : s.n));
+    }
+    DeviceGuard g(ctx->device);
+    const int st = upload_table(ctx, B);
+    if (st != C2D_OK) { release(B); return st; }
+    *out = B;
+    return C2D_OK;
+}
+
+int c2d_poly_bins_destroy(c2d_ctx* ctx, c2d_poly_bins* bins)
+{
+    if (!bins) return C2D_OK;
+    DeviceGuard g(ctx ? ctx->device : bins->device);
+    release(bins);
+    return C2D_OK;
+}
+
+size_t c2d_poly_bins_size(const c2d_poly_bins* bins) { return bins ? bins->bins.size() : 0; }
+size_t c2d_poly_bins_pairs(const c2d_poly_bins* bins) { return bins ? bins->pairs : 0; }
+size_t c2d_poly_bins_bytes(const c2d_poly_bins* bins) { return bins ? bins->bytes : 0; }
+
+int c2d_poly_bins_get(const c2d_poly_bins* bins, size_t i, c2d_poly_bin* out)
+{
+    if (!bins || !out || i >= bins->bins.size()) return C2D_ERR_INVALID_ARG;
+    *out = bins->bins[i];
+    out->stride = bins->strides[i];
+    return C2D_OK;
+}
+
+int c2d_sat_poly_pairs_binned(c2d_ctx* ctx, const c2d_poly_bins* bins, unsigned long long* d_count, c2d_stream stream)
+{
+    if (!ctx) return C2D_ERR_INVALID_ARG;
+    if (!bins) return fail_arg(ctx, "c2d_sat_poly_pairs_binned: NULL bins");
+    if (bins->device != ctx->device) return fail_arg(ctx, "c2d_sat_poly_pairs_binned: the bins belong to another device");
+    if (bins->n_tiles == 0) return C2D_OK;
+    DeviceGuard g(ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    if (int rc = workspace_acquire(ctx, s, d_count != nullptr)) return rc;
+    for (size_t t0 = 0; t0 < bins->n_tiles; t0 += (size_t)kMaxGrid) {
+        const size_t grid = std::min(bins->n_tiles - t0, (size_t)kMaxGrid);
+        hipLaunchKernelGGL(sat_poly_binned_kernel, dim3((unsigned)grid), dim3(64), 0, s, bins->d_table, bins->d_tile_bin, (uint32_t)t0, d_count,
+                           ctx->d_count_words2, ctx->d_async_err);
+    }
+    C2D_LAUNCH_CHECK(ctx);
+    workspace_release(ctx, s, d_count != nullptr);
+    return C2D_OK;
+}
+
+int c2d_poly_bins_from_padded(c2d_ctx* ctx, const float* d_vx, const float* d_vy, const uint8_t* d_k, size_t n, int rows, int granularity,
+                              c2d_poly_bins** out, c2d_stream stream)
+{
+    if (!ctx || !out) return C2D_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (rows < 1 || rows > C2D_POLY_KMAX) return fail_arg(ctx, "c2d_poly_bins_from_padded: rows must be 1..C2D_POLY_KMAX");
+    if (granularity < 1 || granularity > C2D_POLY_KMAX) return fail_arg(ctx, "c2d_poly_bins_from_padded: granularity must be 1..C2D_POLY_KMAX");
+    if (n > 0xffffffffull - 64) return fail_arg(ctx, "c2d_poly_bins_from_padded: at most 2^32 - 65 pairs");
+    if (n && (!d_vx || !d_vy || !d_k)) return fail_arg(ctx, "c2d_poly_bins_from_padded: NULL argument");
+    DeviceGuard g(ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    c2d_poly_bins* B = new (std::nothrow) c2d_poly_bins();
+    if (!B) return C2D_ERR_NOMEM;
+    B->device = ctx->device;
+    B->n_input = n;
+    if (n == 0) { *out = B; return C2D_OK; }
+    auto fail = [&](int st) { release(B); return st; };
+#define C2D_BIN_HIP(call)                                                                        \
+    do {                                                                                         \
+        hipError_t e__ = (call);                                                                 \
+        if (e__ != hipSuccess) return fail(c2d::fail_hip(ctx, e__, #call, __FILE__, __LINE__));  \
+    } while (0)
+    // ---- 1. pairs per (block of 1024, class), prefixes over the blocks, class totals
+    const size_t n_blocks = (n + kBinBlock - 1) / kBinBlock;
+    uint32_t* d_hist = nullptr;   // [n_blocks][256] counts -> prefixes, then [256] totals + 1 word of bad-count waves
+    C2D_BIN_HIP(hipMalloc(&d_hist, (n_blocks * 256 + 257) * sizeof(uint32_t)));
+    uint32_t* d_totals = d_hist + n_blocks * 256;
+    uint32_t hist[257];
+    hipError_t e = hipMemsetAsync(d_totals, 0, 257 * sizeof(uint32_t), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(poly_bin_count_kernel, dim3((unsigned)n_blocks), dim3(kBinBlock), 0, s, d_k, n, rows, granularity, d_hist, d_totals + 256);
+        hipLaunchKernelGGL(poly_bin_scan_kernel, dim3(256), dim3(256), 0, s, d_hist, (uint32_t)n_blocks, d_totals);
+        e = hipMemcpyAsync(hist, d_totals, sizeof hist, hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { (void)hipFree(d_hist); return fail(c2d::fail_hip(ctx, e, "class count", __FILE__, __LINE__)); }
+    struct HistGuard { uint32_t* p; ~HistGuard() { (void)hipFree(p); } } hist_guard{d_hist};
+    B->had_bad_counts = hist[256] != 0;
+    // ---- 2. layout of the block: per bin ax, ay, bx, by (stride = n rounded up to 64 elements, every plane 256-byte
+    // aligned), counts (only when a bin can hold different sizes); then every bin's results back to back; then the index
+    const int g_ = granularity;
+    const bool counted = g_ > 1;
+    std::vector<uint16_t> class_to_bin(256, 0xffff);
+    std::vector<uint32_t> pair_base;
+    size_t bytes = 0, pairs = 0;
+    auto align_up = [](size_t v, size_t a) { return (v + a - 1) / a * a; };
+    struct Plan { size_t ax, ay, bx, by, ka, kb; uint32_t stride; };
+    std::vector<Plan> plan;
+    for (int c = 0; c < 256; c++) {
+        if (!hist[c]) continue;
+        c2d_poly_bin b{};
+        b.rows_a = (uint32_t)std::min(rows, (c / 16 + 1) * g_);
+        b.rows_b = (uint32_t)std::min(rows, (c % 16 + 1) * g_);
+        b.n = hist[c];
+        const uint32_t stride = (uint32_t)align_up(b.n, 64);
+        Plan p{};
+        p.stride = stride;
+        const size_t plane_a = (size_t)b.rows_a * stride * 4, plane_b = (size_t)b.rows_b * stride * 4;
+        p.ax = bytes; bytes = align_up(bytes + plane_a, 256);
+        p.ay = bytes; bytes = align_up(bytes + plane_a, 256);
+        p.bx = bytes; bytes = align_up(bytes + plane_b, 256);
+        p.by = bytes; bytes = align_up(bytes + plane_b, 256);
+        if (counted) {
+            p.ka = bytes; bytes = align_up(bytes + b.n, 256);
+            p.kb = bytes; bytes = align_up(bytes + b.n, 256);
+        }
+        class_to_bin[c] = (uint16_t)B->bins.size();
+        pair_base.push_back((uint32_t)pairs);
+        pairs += b.n;
+        B->bins.push_back(b);
+        B->strides.push_back(stride);
+        plan.push_back(p);
+    }
+    const size_t off_out = bytes;
+    bytes = align_up(bytes + pairs, 256);
+    const size_t off_index = bytes;
+    bytes += n * sizeof(uint32_t);
+    const size_t n_bins = B->bins.size();
+    const size_t off_base = align_up(bytes, 256);
+    bytes = off_base + (n_bins + 1) * sizeof(uint32_t);
+    const size_t off_c2b = align_up(bytes, 256);
+    bytes = off_c2b + 256 * sizeof(uint16_t);
+    hipError_t me = hipMalloc(&B->d_block, bytes);
+    if (me == hipErrorOutOfMemory) { ctx->last_error = "c2d_poly_bins_from_padded: out of device memory"; return fail(C2D_ERR_NOMEM); }
+    if (me != hipSuccess) return fail(c2d::fail_hip(ctx, me, "hipMalloc", __FILE__, __LINE__));
+    char* base = static_cast<char*>(B->d_block);
+    B->d_out_all = reinterpret_cast<uint8_t*>(base + off_out);
+    B->d_index = reinterpret_cast<uint32_t*>(base + off_index);
+    for (size_t b = 0; b < n_bins; b++) {
+        c2d_poly_bin& d = B->bins[b];
+        const Plan& p = plan[b];
+        d.d_ax = reinterpret_cast<const float*>(base + p.ax);
+        d.d_ay = reinterpret_cast<const float*>(base + p.ay);
+        d.d_bx = reinterpret_cast<const float*>(base + p.bx);
+        d.d_by = reinterpret_cast<const float*>(base + p.by);
+        d.d_ka = counted ? reinterpret_cast<const uint8_t*>(base + p.ka) : nullptr;
+        d.d_kb = counted ? reinterpret_cast<const uint8_t*>(base + p.kb) : nullptr;
+        d.d_out = B->d_out_all + pair_base[b];
+        d.stride = p.stride;
+    }
+    int st = upload_table(ctx, B);
+    if (st != C2D_OK) return fail(st);
+    // the move kernel's view of the bins: polygon A = the input's polygon A
+    std::vector<BinDesc> plain(n_bins);
+    for (size_t b = 0; b < n_bins; b++) {
+        const c2d_poly_bin& d = B->bins[b];
+        BinDesc& t = plain[b];
+        t.ax = d.d_ax; t.ay = d.d_ay; t.bx = d.d_bx; t.by = d.d_by; t.ka = d.d_ka; t.kb = d.d_kb; t.out = d.d_out;
+        t.n = (uint32_t)d.n; t.stride = (uint32_t)d.stride; t.tile0 = 0; t.rows_a = (uint16_t)d.rows_a; t.rows_b = (uint16_t)d.rows_b;
+    }
+    BinDesc* d_plain = nullptr;
+    C2D_BIN_HIP(hipMalloc(&d_plain, std::max<size_t>(n_bins, 1) * sizeof(BinDesc)));
+    struct PlainGuard { BinDesc* p; ~PlainGuard() { (void)hipFree(p); } } plain_guard{d_plain};
+    if (n_bins) C2D_BIN_HIP(hipMemcpyAsync(d_plain, plain.data(), n_bins * sizeof(BinDesc), hipMemcpyHostToDevice, s));
+    // ---- 3. move the vertices
+    C2D_BIN_HIP(hipMemsetAsync(B->d_out_all, 0, pairs, s));
+    if (n_bins) C2D_BIN_HIP(hipMemcpyAsync(base + off_base, pair_base.data(), n_bins * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    C2D_BIN_HIP(hipMemcpyAsync(base + off_c2b, class_to_bin.data(), 256 * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+    BinMoveArgs A;
+    A.vx = d_vx; A.vy = d_vy; A.k = d_k; A.n = n; A.rows = rows; A.g = g_;
+    A.table = d_plain;
+    A.class_to_bin = reinterpret_cast<const uint16_t*>(base + off_c2b);
+    A.pair_base = reinterpret_cast<const uint32_t*>(base + off_base);
+    A.block_prefix = d_hist;
+    A.index = B->d_index;
+    hipLaunchKernelGGL(poly_bin_move_kernel, dim3((unsigned)n_blocks), dim3(kBinBlock), 0, s, A);  // (n < 2^32: n_blocks < 2^22)
+    C2D_BIN_HIP(hipStreamSynchronize(s));  // (the host vectors above must outlive their copies)
+#undef C2D_BIN_HIP
+    if (B->had_bad_counts) {
+        release(B);
+        return fail_arg(ctx, "c2d_poly_bins_from_padded: polygon vertex count outside 1..rows");
+    }
+    *out = B;
+    return C2D_OK;
+}
+
+int c2d_poly_bins_results(c2d_ctx* ctx, const c2d_poly_bins* bins, uint8_t* d_out, c2d_stream stream)
+{
+    if (!ctx) return C2D_ERR_INVALID_ARG;
+    if (!bins || !bins->d_index) return fail_arg(ctx, "c2d_poly_bins_results: the handle was not made by c2d_poly_bins_from_padded");
+    if (bins->n_input == 0) return C2D_OK;
+    if (!d_out) return fail_arg(ctx, "c2d_poly_bins_results: NULL output");
+    DeviceGuard g(ctx->device);
+    hipLaunchKernelGGL(poly_bins_results_kernel, dim3(grid_for(bins->n_input, 256, ctx->prop.multiProcessorCount * 16)), dim3(256), 0, (hipStream_t)stream,
+                       bins->d_out_all, bins->d_index, bins->n_input, d_out);
+    C2D_LAUNCH_CHECK(ctx);
+    return C2D_OK;
+}
+
+}  // extern "C"

@@ -196,6 +196,71 @@ int c2d_sat_poly_pairs_rows(c2d_ctx* ctx, const float* d_vx, const float* d_vy, 
                             size_t n, int rows, uint8_t* d_out, unsigned long long* d_count,
                             c2d_stream stream);
 
+/* ---- binned polygon batches ---------------------------------------------------
+ * The padded layout above moves 16 vertex rows per polygon whatever the polygons are: with
+ * K ~ U{3..16} that is 259 bytes per pair for 155 bytes of real vertices, and no kernel can
+ * avoid it — the pairs of a wave have unrelated counts, so every 64-byte segment of every row
+ * holds a vertex somebody needs.  A caller that keeps its pairs in BINS — pairs grouped by the
+ * size of their polygons, each bin a tight plane layout of its own — hands over the exact
+ * bytes instead, and the bin's row counts are known before any count byte has been read:
+ *
+ *   bin:  rows_a, rows_b        vertex rows of polygon A / B in this bin, 1..C2D_POLY_KMAX
+ *         n                     pairs in the bin (any number, < 2^32)
+ *         stride                elements between the vertex rows of a plane (0 = n; a multiple of 64
+ *                               with 256-byte aligned planes keeps every row segment aligned)
+ *         d_ax, d_ay            f32[rows_a][stride]  polygon A's vertices, pair index fastest
+ *         d_bx, d_by            f32[rows_b][stride]  polygon B's
+ *         d_ka, d_kb            u8[n] vertex counts 1..rows_a / 1..rows_b, or NULL = every
+ *                               polygon of the bin has exactly rows_a / rows_b vertices
+ *         d_out                 u8[n] results
+ *
+ * Same arithmetic and the same results as c2d_sat_poly_pairs for the same polygons (true normals,
+ * unfused projections, strict <; SAT is symmetric in A and B, so a producer may swap the two
+ * polygons of a pair to halve the number of bins).  Any number of bins (up to 65535), any
+ * mix of row counts; ONE launch covers all of them.
+ *
+ *   c2d_poly_bins_create   validates the descriptors and uploads the launch table (synchronous;
+ *                          the buffers stay the caller's and may be refilled between tests: the
+ *                          table holds pointers and sizes, not data);
+ *   c2d_sat_poly_pairs_binned   tests every pair of every bin: asynchronous on `stream`,
+ *                          graph-capturable; vertex counts are checked on the device as for
+ *                          c2d_sat_poly_pairs (pair reads 0, error at the next synchronise);
+ *   c2d_poly_bins_from_padded   bins a padded batch (the layout of c2d_sat_poly_pairs_rows) on the
+ *                          device: polygon sizes are rounded up to a multiple of `granularity`
+ *                          rows (1 = one bin per (ka, kb), no padding at all; 4 = at most 16 bins),
+ *                          the bins live in ONE device block owned by the handle.  This moves
+ *                          every vertex once (it costs a few tests): it pays when the
+ *                          batch is tested more than once or as a converter for stored datasets;
+ *                          a producer that can write bins directly should.  Synchronous; a vertex
+ *                          count outside 1..rows is refused (C2D_ERR_INVALID_ARG, no handle).
+ *   c2d_poly_bins_results  for a handle made by c2d_poly_bins_from_padded: the results in the
+ *                          ORDER OF THE PADDED INPUT, u8[n] (asynchronous on `stream`);
+ *   c2d_poly_bins_get      descriptor i of the handle (device pointers), for inspection. */
+typedef struct c2d_poly_bin {
+    uint32_t rows_a, rows_b;
+    size_t n;
+    size_t stride;   /* elements between consecutive vertex rows of a plane, >= n; 0 = n */
+    const float* d_ax;
+    const float* d_ay;
+    const float* d_bx;
+    const float* d_by;
+    const uint8_t* d_ka;
+    const uint8_t* d_kb;
+    uint8_t* d_out;
+} c2d_poly_bin;
+typedef struct c2d_poly_bins c2d_poly_bins;
+int c2d_poly_bins_create(c2d_ctx* ctx, const c2d_poly_bin* bins, size_t n_bins, c2d_poly_bins** out);
+int c2d_poly_bins_from_padded(c2d_ctx* ctx, const float* d_vx, const float* d_vy, const uint8_t* d_k, size_t n,
+                              int rows, int granularity, c2d_poly_bins** out, c2d_stream stream);
+int c2d_poly_bins_destroy(c2d_ctx* ctx, c2d_poly_bins* bins);
+size_t c2d_poly_bins_size(const c2d_poly_bins* bins);   /* number of bins  */
+size_t c2d_poly_bins_pairs(const c2d_poly_bins* bins);  /* pairs in total  */
+size_t c2d_poly_bins_bytes(const c2d_poly_bins* bins);  /* bytes one test moves: vertices, counts, results */
+int c2d_poly_bins_get(const c2d_poly_bins* bins, size_t i, c2d_poly_bin* out);
+int c2d_sat_poly_pairs_binned(c2d_ctx* ctx, const c2d_poly_bins* bins, unsigned long long* d_count,
+                              c2d_stream stream);
+int c2d_poly_bins_results(c2d_ctx* ctx, const c2d_poly_bins* bins, uint8_t* d_out, c2d_stream stream);
+
 /* ---- random stream -----------------------------------------------------------
  * Replaces setup_kernel + curand_normal (utils.cu:111-117, :146-150).  The
  * generator is counter based: Philox4x32-10 with key = seed and subsequence =
