@@ -147,6 +147,8 @@ def main() -> None:
     ap.add_argument("--scenes-max-samples", type=int, default=120_000)
     ap.add_argument("--poly-pairs", type=int, default=10_000_000, help="config 5 polygon pairs per GPU; 0 = skip the leg")
     ap.add_argument("--poly-reps", type=int, default=20)
+    ap.add_argument("--poly-bin-granularity", type=int, default=1,
+                    help="binned polygon leg: polygon sizes rounded up to this many rows per bin (1 = one bin per (ka, kb): the exact bytes)")
     args = ap.parse_args()
 
     launched = "WORLD_SIZE" in os.environ or "RANK" in os.environ
@@ -568,6 +570,66 @@ def main() -> None:
             if c.get("hbm_bytes_per_launch"):
                 poly_leg["roofline"]["traffic"] = c["hbm_bytes_per_launch"]
                 poly_leg["roofline"]["traffic_source"] = "recorded, not measured in this run: %s" % c.get("source")
+        # ---- the same 1e7 pairs as a BINNED batch (include/c2d.h "binned polygon batches"): one bin per (ka, kb), so the bytes
+        # that move are the vertices (+ one result byte).  The binning pass is a one-off conversion, timed separately.
+        torch.cuda.synchronize()
+        tb0 = time.perf_counter()
+        bins = eng.poly_bins_from_padded(vx.data_ptr(), vy.data_ptr(), kk.data_ptr(), npoly, KMAX, args.poly_bin_granularity, stream=sh)
+        bin_ms = (time.perf_counter() - tb0) * 1e3
+        bcnt = torch.zeros(1, dtype=torch.int64, device=dev)
+
+        def binned_step():
+            eng.sat_poly_pairs_binned(bins, bcnt.data_ptr(), stream=sh)
+
+        prewarm(binned_step)
+        torch.cuda.synchronize()
+        bcnt.zero_()
+        barrier()
+        torch.cuda.synchronize()
+        b0 = time.perf_counter()
+        w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        w0.record(stream)
+        for _ in range(preps):
+            binned_step()
+        w1.record(stream)
+        all_reduce_sum(bcnt)
+        torch.cuda.synchronize()
+        barrier()
+        bel = shd.max_over_ranks(time.perf_counter() - b0, dev)
+        eng.check_async()
+        binned_ms = w0.elapsed_time(w1) / preps
+        bout = torch.empty(npoly, dtype=torch.uint8, device=dev)
+        bins.results(bout.data_ptr(), stream=sh)
+        torch.cuda.synchronize()
+        same = int((bout == pout).sum().item())
+        if same != npoly:
+            raise SystemExit(f"PARITY FAILURE: the binned polygon path differs from the padded one on {npoly - same} of {npoly} pairs")
+        moved = bins.bytes
+        exact_gbs = exact_bytes / (binned_ms * 1e-3) / 1e9
+        poly_leg["binned"] = {"metric": "poly_pair_tests_per_s (binned batch, one bin per (ka, kb))" if args.poly_bin_granularity == 1 else
+                                        f"poly_pair_tests_per_s (binned batch, sizes rounded up to {args.poly_bin_granularity} rows)",
+                              "value": npoly * world * preps / bel, "kernel_ms": round(binned_ms, 5), "ms_per_pass": bel / preps * 1e3, "bins": len(bins),
+                              "collide_rate": float(bcnt.item()) / (npoly * world * preps), "bytes_moved_per_pair": moved / npoly,
+                              "roofline": {"bound": "hbm", "kernel": "sat_poly_binned_kernel", "achieved": round(exact_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": round(exact_gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": exact_bytes,
+                                           "bytes_note": "EXACT bytes of the workload: 8 B per real vertex + 2 count bytes + 1 result byte per pair (SURVEY.md §8d); "
+                                                         "the bins themselves move %.1f B/pair" % (moved / npoly),
+                                           "traffic": None, "step_ms_distribution": step_distribution(binned_step, preps)},
+                              "binning_pass_ms": round(bin_ms, 3),
+                              "binning_note": "c2d_poly_bins_from_padded: one-off conversion of the padded batch (a stable counting sort that moves every vertex "
+                                              "once), not part of a test; results are returned in the padded order by c2d_poly_bins_results",
+                              "parity": f"booleans equal to the padded entry point's on {same} of {npoly} pairs"}
+        c = counts.get("sat_poly_binned.config5")
+        if c and npoly == c.get("pairs") and args.poly_bin_granularity == 1:
+            lane = npoly / (binned_ms * 1e-3) * c["valu_instr_per_pair"] / 1e12
+            poly_leg["binned"]["valu_roofline"] = {"bound": "valu", "achieved": round(lane, 2), "peak": VALU_PEAK_TLANE, "unit": "T VALU lane-instr/s",
+                                                   "frac": round(lane / VALU_PEAK_TLANE, 4), "valu_instr_per_pair": c["valu_instr_per_pair"],
+                                                   "instr_source": c.get("source")}
+            if c.get("hbm_bytes_per_launch"):
+                poly_leg["binned"]["roofline"]["traffic"] = c["hbm_bytes_per_launch"]
+                poly_leg["binned"]["roofline"]["traffic_source"] = "recorded, not measured in this run: %s" % c.get("source")
+        bins.close()
+        del bout
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             poly_keep = (vx.cpu().numpy(), vy.cpu().numpy(), kk.cpu().numpy(), pout.cpu().numpy())
         del vx, vy, kk

@@ -41,6 +41,10 @@ struct Scene {
     // Radius-only form of the same pretest: raw word x >= x0 (and use_x0) proves a miss
     uint32_t x0;
     bool use_x0;
+    // Certificates for the second axis of each parallel pair (sample_collides_mask): a rectangle's edge axes 2, 3 are the
+    // negatives of axes 0, 1 up to rounding, so when the two intervals overlap by enough on axis i, axis i + 2 cannot separate
+    float skip_lo[2], skip_hi[2];  // robot axes: obstacle interval must reach [.., skip_lo] and [skip_hi, ..] on axis 0 / 1
+    float skip_c2, skip_c3;        // obstacle axes: needed overlap = c2 |a + b|_1 + c3 |a|_1 (a, b: the two axes of the pair)
     // use_x0 == false && x0 == 0 marks a scene that is not "tame": some parameter is NaN, infinite or >= 1e15 in
     // magnitude, so a sampled vertex or a projection may be non-finite.  Such a scene takes wave_count_hits_plain: no
     // pretest (their proofs assume numbers) and the axis test that restores minmax_element's behaviour on a NaN first
@@ -53,7 +57,7 @@ struct Scene {
 // |sin|, |cos| <= 1 + 2^-22.
 constexpr float kNormalMax = 6.77f;
 
-C2D_DEV Scene make_scene(float robot_w, float robot_h, float px, float py, const Pose& pose, const StdDev& sd)
+C2D_DEV Scene make_scene_values(float robot_w, float robot_h, float px, float py, const Pose& pose, const StdDev& sd)
 {
     Scene sc;
     float s, c;
@@ -80,13 +84,34 @@ C2D_DEV Scene make_scene(float robot_w, float robot_h, float px, float py, const
     const float hym = __builtin_fabsf(sc.hh) + 0.5f * kNormalMax * __builtin_fabsf(sc.sh);
     const float rho = __builtin_sqrtf(hxm * hxm + hym * hym);
     const float D = kNormalMax * (__builtin_fabsf(sc.sx) + __builtin_fabsf(sc.sy));
+    // ---- certificates for the parallel axes (derivation at sample_collides_mask).  C bounds every coordinate of the
+    // robot and of any sampled obstacle: |o| <= |centre| + |c hx| + |s hy| <= 6.77 sigma + hxm + hym (|draw| <= kNormalMax)
+    float cmax = kNormalMax * __builtin_fmaxf(__builtin_fabsf(sc.sx), __builtin_fabsf(sc.sy)) + (hxm + hym);
+#pragma unroll
+    for (int k = 0; k < 8; k++) cmax = __builtin_fmaxf(cmax, __builtin_fabsf(sc.robot[k]));
+    cmax *= 1.0f + 0x1p-10f;
+    sc.skip_c2 = (2.0f + 0x1p-8f) * cmax;
+    sc.skip_c3 = (8.0f + 0x1p-6f) * 0x1p-24f * cmax;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
         const float ax = sc.robot[2 * i + 2] - sc.robot[2 * i];
         const float ay = sc.robot[2 * i + 3] - sc.robot[2 * i + 1];
-        const float p0 = ax * sc.robot[0] + ay * sc.robot[1], p1 = ax * sc.robot[2] + ay * sc.robot[3];
-        const float p2 = ax * sc.robot[4] + ay * sc.robot[5], p3 = ax * sc.robot[6] + ay * sc.robot[7];
+        // the robot's own interval on its axis i: the very floats the SAT computes (dot2)
+        const float p0 = dot2(ax, sc.robot[0], ay, sc.robot[1]), p1 = dot2(ax, sc.robot[2], ay, sc.robot[3]);
+        const float p2 = dot2(ax, sc.robot[4], ay, sc.robot[5]), p3 = dot2(ax, sc.robot[6], ay, sc.robot[7]);
         const float rmin = min4(p0, p1, p2, p3), rmax = max4(p0, p1, p2, p3);
+        {
+            const float bx = sc.robot[(2 * i + 6) & 7] - sc.robot[2 * i + 4], by = sc.robot[(2 * i + 7) & 7] - sc.robot[2 * i + 5];  // axis i + 2
+            const float need = (__builtin_fabsf(ax + bx) + __builtin_fabsf(ay + by)) * sc.skip_c2 +
+                               (__builtin_fabsf(ax) + __builtin_fabsf(ay)) * sc.skip_c3 + 1e-36f;
+            const float lo = rmin + need, hi = rmax - need;
+            sc.skip_lo[i] = lo + 0x1p-20f * __builtin_fabsf(lo);
+            sc.skip_hi[i] = hi - 0x1p-20f * __builtin_fabsf(hi);
+            if (ax == -bx && ay == -by) {  // exactly opposite: every projection is the exact negative, axis i + 2 repeats axis i's two comparisons
+                sc.skip_lo[i] = -__builtin_inff();
+                sc.skip_hi[i] = __builtin_inff();
+            }
+        }
         const float n2 = __builtin_sqrtf(ax * ax + ay * ay), n1 = __builtin_fabsf(ax) + __builtin_fabsf(ay);
         const float M = (n2 * rho) * (1.0f + 0x1p-10f) + 0x1p-12f * (n1 * (rho + D));
         const float hi = rmax + M, lo = rmin - M;
@@ -135,6 +160,34 @@ C2D_DEV Scene make_scene(float robot_w, float robot_h, float px, float py, const
             sc.use_x0 = true;
         }
     }
+    return sc;
+}
+
+// The scene is wave-uniform, but gfx950's scalar unit has no floating point: computed by the vector unit, every field
+// sits in a VGPR of its own (the same value in all 64 lanes) for as long as the sample loops run — three dozen of the
+// kernels' 80 registers, and the reason for their dozen spilled dwords.  Moving the fields into scalar registers
+// (v_readfirstlane; -DC2D_MC_SCENE_IN_SGPRS) was measured and is NOT the default: it frees the VGPRs (mc_pair_kernel 92 -> 72,
+// no scratch left in the advance kernels) but the kernels already use every SGPR for lane masks and arguments, so 30 to 60
+// scalars spill to VGPR lanes instead and come back through v_readlane inside the sample loops: config-3 scene 0.547 ->
+// 0.585 ms, config-4 shard 382 -> 400 ms; 7 or 8 waves per SIMD on top of it are slower still (profiles/r03_mc_isa.md).
+C2D_DEV float to_sgpr(float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); }
+
+C2D_DEV Scene make_scene(float robot_w, float robot_h, float px, float py, const Pose& pose, const StdDev& sd)
+{
+    Scene sc = make_scene_values(robot_w, robot_h, px, py, pose, sd);
+#ifdef C2D_MC_SCENE_IN_SGPRS
+#pragma unroll
+    for (int k = 0; k < 8; k++) sc.robot[k] = to_sgpr(sc.robot[k]);
+    sc.hw = to_sgpr(sc.hw); sc.hh = to_sgpr(sc.hh);
+    sc.sx = to_sgpr(sc.sx); sc.sy = to_sgpr(sc.sy); sc.st = to_sgpr(sc.st); sc.sw = to_sgpr(sc.sw); sc.sh = to_sgpr(sc.sh);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        sc.pax[i] = to_sgpr(sc.pax[i]); sc.pay[i] = to_sgpr(sc.pay[i]); sc.plo[i] = to_sgpr(sc.plo[i]); sc.phi[i] = to_sgpr(sc.phi[i]);
+        sc.skip_lo[i] = to_sgpr(sc.skip_lo[i]); sc.skip_hi[i] = to_sgpr(sc.skip_hi[i]);
+    }
+    sc.skip_c2 = to_sgpr(sc.skip_c2); sc.skip_c3 = to_sgpr(sc.skip_c3);
+    sc.x0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sc.x0);
+#endif
     return sc;
 }
 
@@ -212,11 +265,28 @@ C2D_DEV unsigned long long axis_separates_mask(float ax, float ay, const float (
     return __builtin_amdgcn_ballot_w64(max1 < min2) | __builtin_amdgcn_ballot_w64(max2 < min1);
 }
 
-// lanes whose sample collides (no axis separates it)
+// lanes whose sample collides (no axis separates it): convex_collide(robot, obstacle), utils.cu:159-184.
+//
+// All eight axes are part of the reference's result.  Two kinds of work are left out here, neither of which can change a
+// lane's answer:
+//  * once every lane of the wave is separated, the remaining axes are skipped (checked after the robot's and after the
+//    obstacle's first axis pair);
+//  * a rectangle's edge axes 2, 3 are the negatives of its axes 0, 1 up to rounding: b = -a + d with |d| a few ulps of the
+//    coordinates.  For every vertex v the computed projections satisfy |p_b(v) + p_a(v)| <= eta,
+//        eta = |d|_1 C (1 + 3u) + 4u (1 + u) |a|_1 C,        u = 2^-24, C >= every |coordinate|,
+//    (d.v plus the roundings of the two dot products, 2u (|a_x v_x| + |a_y v_y|) each), hence max1_b >= -min1_a - eta,
+//    min2_b <= -max2_a + eta and likewise with 1, 2 exchanged: if both overlaps on axis a, max2_a - min1_a and
+//    max1_a - min2_a, are at least 2 eta, NEITHER comparison of utils.cu:178 can hold on axis b.  d is taken from the
+//    floats themselves (a + b, computed per pair of axes), C from the scene (make_scene), the thresholds carry a 2^-8
+//    relative and a 1e-36 absolute allowance for their own rounding and for underflow.  Axis b is evaluated in full
+//    whenever an undecided lane's overlap on axis a is thinner than that (a few waves in a hundred on the bench scenes).
+// Validation builds (C2D_MC_NO_AXIS_SKIP, part of `make lib-nopretest`) evaluate every axis; tests/test_gpu_fullsize.py
+// compares the two builds on whole workloads.
 C2D_DEV unsigned long long sample_collides_mask(const Scene& sc, const float (&o)[8])
 {
     const unsigned long long lanes = wave_lanes();
     unsigned long long sep = 0;
+#ifdef C2D_MC_NO_AXIS_SKIP
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         float ax, ay;
@@ -232,6 +302,56 @@ C2D_DEV unsigned long long sample_collides_mask(const Scene& sc, const float (&o
         if (((C2D_MC_EARLY_MASK >> i) & 1) && (lanes & ~sep) == 0ull) return 0ull;
     }
     return lanes & ~sep;
+#else
+    // ---- robot axes 0, 1 (the robot's own interval is wave-uniform)
+    unsigned long long thin[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const float ax = sc.robot[2 * i + 2] - sc.robot[2 * i], ay = sc.robot[2 * i + 3] - sc.robot[2 * i + 1];
+        const float r0 = dot2(ax, sc.robot[0], ay, sc.robot[1]), r1 = dot2(ax, sc.robot[2], ay, sc.robot[3]);
+        const float r2 = dot2(ax, sc.robot[4], ay, sc.robot[5]), r3 = dot2(ax, sc.robot[6], ay, sc.robot[7]);
+        const float q0 = dot2(ax, o[0], ay, o[1]), q1 = dot2(ax, o[2], ay, o[3]);
+        const float q2 = dot2(ax, o[4], ay, o[5]), q3 = dot2(ax, o[6], ay, o[7]);
+        const float rmin = min4(r0, r1, r2, r3), rmax = max4(r0, r1, r2, r3);
+        const float omin = min4(q0, q1, q2, q3), omax = max4(q0, q1, q2, q3);
+        sep |= __builtin_amdgcn_ballot_w64(rmax < omin) | __builtin_amdgcn_ballot_w64(omax < rmin);
+        thin[i] = __builtin_amdgcn_ballot_w64(omax < sc.skip_lo[i]) | __builtin_amdgcn_ballot_w64(omin > sc.skip_hi[i]);
+    }
+    if ((lanes & ~sep) == 0ull) return 0ull;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        if ((thin[i] & lanes & ~sep) != 0ull) {  // axis i + 2 in full
+            const float ax = sc.robot[(2 * i + 6) & 7] - sc.robot[2 * i + 4], ay = sc.robot[(2 * i + 7) & 7] - sc.robot[2 * i + 5];
+            sep |= axis_separates_mask(ax, ay, sc.robot, o);
+        }
+    }
+    // ---- obstacle axes 4, 5, with the per-sample certificate for 6, 7
+    unsigned long long thin2[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const float ax = o[2 * j + 2] - o[2 * j], ay = o[2 * j + 3] - o[2 * j + 1];
+        const float bx = o[(2 * j + 6) & 7] - o[2 * j + 4], by = o[(2 * j + 7) & 7] - o[2 * j + 5];  // obstacle edge j + 2
+        const float r0 = dot2(ax, sc.robot[0], ay, sc.robot[1]), r1 = dot2(ax, sc.robot[2], ay, sc.robot[3]);
+        const float r2 = dot2(ax, sc.robot[4], ay, sc.robot[5]), r3 = dot2(ax, sc.robot[6], ay, sc.robot[7]);
+        const float q0 = dot2(ax, o[0], ay, o[1]), q1 = dot2(ax, o[2], ay, o[3]);
+        const float q2 = dot2(ax, o[4], ay, o[5]), q3 = dot2(ax, o[6], ay, o[7]);
+        const float min1 = min4(r0, r1, r2, r3), max1 = max4(r0, r1, r2, r3);
+        const float min2 = min4(q0, q1, q2, q3), max2 = max4(q0, q1, q2, q3);
+        sep |= __builtin_amdgcn_ballot_w64(max1 < min2) | __builtin_amdgcn_ballot_w64(max2 < min1);
+        const float need = fma_(__builtin_fabsf(ax) + __builtin_fabsf(ay), sc.skip_c3,
+                                (__builtin_fabsf(ax + bx) + __builtin_fabsf(ay + by)) * sc.skip_c2) + 1e-36f;
+        thin2[j] = __builtin_amdgcn_ballot_w64(max2 - min1 < need) | __builtin_amdgcn_ballot_w64(max1 - min2 < need);
+    }
+    if ((lanes & ~sep) == 0ull) return 0ull;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        if ((thin2[j] & lanes & ~sep) != 0ull) {  // axis j + 6 in full
+            const float bx = o[(2 * j + 6) & 7] - o[2 * j + 4], by = o[(2 * j + 7) & 7] - o[2 * j + 5];
+            sep |= axis_separates_mask(bx, by, sc.robot, o);
+        }
+    }
+    return lanes & ~sep;
+#endif
 }
 
 #ifndef C2D_MC_PRETEST_HOLDOFF
@@ -256,6 +376,9 @@ constexpr int kCandSlots = 64 + 256 * C2D_MC_ILP;  // < 64 left over + every sam
 //    candidates (radius word, offset) wait in `cand` for their angle word / Box-Muller / centre pretest, the undecided
 //    ones among them in `und` for the full evaluation.  Each of these later stages draws the block it needs per sample.
 struct WaveQueue {
+    // The scene fields that only the full evaluation reads (park_scene / load_eval): 24 floats, read back as six
+    // broadcast ds_read_b128 per 64 evaluated samples instead of living in two dozen VGPRs through every sample loop
+    float4 ev[6];
     union {
         struct {
             float4 cw[kQueueSlots];      // dx, dy, bits(radius word 2), bits(angle word 2)
@@ -274,6 +397,61 @@ struct WaveQueue {
     };
 };
 
+// Used by the adaptive kernels, whose register budget (80 VGPRs for six waves per SIMD) the full scene does not fit: with
+// the scene in registers they spill 17-21 dwords and reload some inside the sample loops; parked, no scratch access is left
+// in any sample loop (profiles/r03_mc_isa.md).  The times are the same within 0.5 % (config-4 shard 383 ms either way,
+// reference-default batch 39.4 vs 40.0 ms): the spills were harmless, the parked form is simply the one without them.
+// mc_pair_kernel (92 VGPRs at five waves, nothing spilled) keeps the scene in registers: every sample of the config-3 scene
+// is evaluated in full, and the six LDS reads per evaluation cost it 3 % (0.547 -> 0.564 ms per 1e8 samples).
+// Splits a scene: the fields of the per-sample path (sigma_x, sigma_y, the centre pretest, the radius threshold) stay in
+// registers; the ones only a full evaluation needs (robot, obstacle extents, the other sigmas, the parallel-axis
+// certificates) are parked in the wave's LDS by lane 0 and come back through load_eval right before they are used.
+// Returns the scene with the parked fields cleared, so that their registers are free in between.
+C2D_DEV Scene park_scene(const Scene& sc, WaveQueue& q)
+{
+    if ((threadIdx.x & 63) == 0) {
+        q.ev[0] = make_float4(sc.robot[0], sc.robot[1], sc.robot[2], sc.robot[3]);
+        q.ev[1] = make_float4(sc.robot[4], sc.robot[5], sc.robot[6], sc.robot[7]);
+        q.ev[2] = make_float4(sc.skip_lo[0], sc.skip_lo[1], sc.skip_hi[0], sc.skip_hi[1]);
+        q.ev[3] = make_float4(sc.skip_c2, sc.skip_c3, sc.hw, sc.hh);
+        q.ev[4] = make_float4(sc.st, sc.sw, sc.sh, 0.0f);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    Scene h;
+#pragma unroll
+    for (int k = 0; k < 8; k++) h.robot[k] = 0.0f;
+    h.hw = h.hh = h.st = h.sw = h.sh = 0.0f;
+    h.skip_c2 = h.skip_c3 = 0.0f;
+    h.sx = sc.sx;
+    h.sy = sc.sy;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        h.pax[i] = sc.pax[i]; h.pay[i] = sc.pay[i]; h.plo[i] = sc.plo[i]; h.phi[i] = sc.phi[i];
+        h.skip_lo[i] = h.skip_hi[i] = 0.0f;
+    }
+    h.x0 = sc.x0;
+    h.use_x0 = sc.use_x0;
+    return h;
+}
+
+// the scene with its parked fields read back (the compiler barrier keeps the reads inside the loop they are used in)
+template <bool PARKED>
+C2D_DEV Scene load_eval(const Scene& hot, const WaveQueue& q)
+{
+    if constexpr (!PARKED) return hot;
+    asm volatile("" ::: "memory");
+    Scene sc = hot;
+    const float4 a = q.ev[0], b = q.ev[1], c = q.ev[2], d = q.ev[3], e = q.ev[4];
+    sc.robot[0] = a.x; sc.robot[1] = a.y; sc.robot[2] = a.z; sc.robot[3] = a.w;
+    sc.robot[4] = b.x; sc.robot[5] = b.y; sc.robot[6] = b.z; sc.robot[7] = b.w;
+    sc.skip_lo[0] = c.x; sc.skip_lo[1] = c.y; sc.skip_hi[0] = c.z; sc.skip_hi[1] = c.w;
+    sc.skip_c2 = d.x; sc.skip_c3 = d.y; sc.hw = d.z; sc.hh = d.w;
+    sc.st = e.x; sc.sw = e.y; sc.sh = e.z;
+    return sc;
+}
+
 // ---- NEAR: hits among samples [begin, begin + count) of one scene, computed by one wave.  A lane owns one GROUP of four
 // samples per iteration (draw layout: c2d_math.hpp), so an iteration covers 256 consecutive samples; sub-iteration
 // j = 0..3 handles member j of the 64 groups.  begin and count are arbitrary (a shard may start inside a group):
@@ -283,6 +461,7 @@ struct WaveQueue {
 // expensive piece (Box-Muller of the centre, the full evaluation) exists ONCE in the kernel's code: unrolled over j the
 // kernel was 90 KB, more than the instruction cache holds, and ran 30 % slower than the one-sample-per-lane kernel it
 // replaced.
+template <bool PARKED>
 C2D_DEV uint32_t wave_count_hits_near(const Scene& sc, uint64_t seed, uint64_t scene_id, uint64_t begin, uint32_t count,
                                       WaveQueue& wq)
 {
@@ -410,8 +589,9 @@ C2D_DEV uint32_t wave_count_hits_near(const Scene& sc, uint64_t seed, uint64_t s
                 w2a = __float_as_uint(e.w);
             }
             float o[8];
-            sample_obstacle(sc, w2r, w2a, dx, dy, seed, scene_id, begin + sidx, o);
-            hits += (uint32_t)__popcll(sample_collides_mask(sc, o) & live_m);
+            const Scene ev = load_eval<PARKED>(sc, wq);
+            sample_obstacle(ev, w2r, w2a, dx, dy, seed, scene_id, begin + sidx, o);
+            hits += (uint32_t)__popcll(sample_collides_mask(ev, o) & live_m);
             if (flush) break;
         }
     }
@@ -426,6 +606,7 @@ C2D_DEV uint32_t wave_count_hits_near(const Scene& sc, uint64_t seed, uint64_t s
 //      candidate costs nothing beyond its block;
 //   2  64 candidates: angle word (block 1 of the candidate's group), Box-Muller, centre pretest; the undecided ones queue;
 //   3  64 undecided samples: second pair's block (2 / 3 of the group), full evaluation.
+template <bool PARKED>
 C2D_DEV uint32_t wave_count_hits_far(const Scene& sc, uint64_t seed, uint64_t scene_id, uint64_t begin, uint32_t count,
                                      WaveQueue& wq)
 {
@@ -535,8 +716,9 @@ C2D_DEV uint32_t wave_count_hits_far(const Scene& sc, uint64_t seed, uint64_t sc
             const U4 pb = philox_draw_block(seed, scene_id, s >> 2, 2u + ((uint32_t)(s >> 1) & 1u));
             const bool odd = (s & 1) != 0;
             float o[8];
-            sample_obstacle(sc, odd ? pb.z : pb.x, odd ? pb.w : pb.y, c.x, c.y, seed, scene_id, s, o);
-            hits += (uint32_t)__popcll(sample_collides_mask(sc, o) & live_m);
+            const Scene ev = load_eval<PARKED>(sc, wq);
+            sample_obstacle(ev, odd ? pb.z : pb.x, odd ? pb.w : pb.y, c.x, c.y, seed, scene_id, s, o);
+            hits += (uint32_t)__popcll(sample_collides_mask(ev, o) & live_m);
         }
         if (drained && cn == 0 && un == 0) break;
     }
@@ -547,7 +729,8 @@ C2D_DEV uint32_t wave_count_hits_far(const Scene& sc, uint64_t seed, uint64_t sc
 // ---- PLAIN: a scene that is not tame (Scene::tame).  One sample per lane, every sample evaluated in full with the
 // axis test that is defined for every bit pattern (rect_collide, c2d_math.hpp); each lane draws its own blocks.  Slow
 // (four Philox blocks per sample) and rare by construction: tables of finite numbers never come here.
-C2D_DEV uint32_t wave_count_hits_plain(const Scene& sc, uint64_t seed, uint64_t scene_id, uint64_t begin, uint32_t count)
+template <bool PARKED>
+C2D_DEV uint32_t wave_count_hits_plain(const Scene& sc, uint64_t seed, uint64_t scene_id, uint64_t begin, uint32_t count, const WaveQueue& wq)
 {
     const uint32_t lane = threadIdx.x & 63;
     uint32_t hits = 0;
@@ -560,21 +743,23 @@ C2D_DEV uint32_t wave_count_hits_plain(const Scene& sc, uint64_t seed, uint64_t 
         const U4 b2 = philox_draw_block(seed, scene_id, s >> 2, 2u + (j >> 1));
         float dx, dy, o[8];
         sample_centre(sc, u4_word(b0, (int)j), u4_word(b1, (int)j), dx, dy);
-        sample_obstacle(sc, (j & 1u) ? b2.z : b2.x, (j & 1u) ? b2.w : b2.y, dx, dy, seed, scene_id, s, o);
-        hits += (uint32_t)__popcll(__ballot(live && rect_collide(sc.robot, o)));
+        const Scene ev = load_eval<PARKED>(sc, wq);
+        sample_obstacle(ev, (j & 1u) ? b2.z : b2.x, (j & 1u) ? b2.w : b2.y, dx, dy, seed, scene_id, s, o);
+        hits += (uint32_t)__popcll(__ballot(live && rect_collide(ev.robot, o)));
     }
     return hits;
 }
 
 // hits among samples [begin, begin + count) of one scene, computed by one wave
+template <bool PARKED>
 C2D_DEV uint32_t wave_count_hits(const Scene& sc, uint64_t seed, uint64_t scene_id, uint64_t begin, uint32_t count,
                                  WaveQueue& q)
 {
-    if (!sc.tame()) return wave_count_hits_plain(sc, seed, scene_id, begin, count);
+    if (!sc.tame()) return wave_count_hits_plain<PARKED>(sc, seed, scene_id, begin, count, q);
 #ifndef C2D_MC_NO_PRETEST  // validation builds evaluate every sample in full
-    if (sc.use_x0 && sc.x0 < kFarX0) return wave_count_hits_far(sc, seed, scene_id, begin, count, q);
+    if (sc.use_x0 && sc.x0 < kFarX0) return wave_count_hits_far<PARKED>(sc, seed, scene_id, begin, count, q);
 #endif
-    return wave_count_hits_near(sc, seed, scene_id, begin, count, q);
+    return wave_count_hits_near<PARKED>(sc, seed, scene_id, begin, count, q);
 }
 
 // ---- one scene, sample-parallel (BASELINE config 3) -------------------------------
@@ -592,15 +777,15 @@ struct PairArgs {
 __global__ __launch_bounds__(kMcBlock, C2D_MC_PAIR_WAVES) void mc_pair_kernel(PairArgs A, unsigned long long* __restrict__ d_hits)
 {
     __shared__ WaveQueue s_queue[kWavesPerBlock];
-    const Scene sc = make_scene(A.robot_w, A.robot_h, A.px, A.py, A.pose, A.sd);
-    const uint64_t n_chunks = (A.n_samples + A.chunk - 1) / A.chunk;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const Scene sc = make_scene(A.robot_w, A.robot_h, A.px, A.py, A.pose, A.sd);  // (not parked: see park_scene)
+    const uint64_t n_chunks = (A.n_samples + A.chunk - 1) / A.chunk;
     unsigned long long total = 0;
     for (uint64_t ch = (uint64_t)blockIdx.x * kWavesPerBlock + wave; ch < n_chunks; ch += (uint64_t)gridDim.x * kWavesPerBlock) {
         const uint64_t off = ch * A.chunk;
         const uint64_t left = A.n_samples - off;
         const uint32_t count = left < A.chunk ? (uint32_t)left : A.chunk;
-        total += wave_count_hits(sc, A.seed, A.scene_id, A.sample_begin + off, count, s_queue[wave]);
+        total += wave_count_hits<false>(sc, A.seed, A.scene_id, A.sample_begin + off, count, s_queue[wave]);
     }
     if ((threadIdx.x & 63) == 0 && total) atomicAdd(d_hits, total);
 }
@@ -722,12 +907,12 @@ __global__ __launch_bounds__(kMcBlock, C2D_MC_ADV_WAVES) void mc_scenes_advance_
             uint32_t pi = (uint32_t)(int)row.pose_idx, vi = (uint32_t)(int)row.var_idx;
             pi = pi < A.num_poses ? pi : A.num_poses - 1;
             vi = vi < A.num_std_devs ? vi : A.num_std_devs - 1;
-            const Scene sc = make_scene(A.robot_w, A.robot_h, row.x, row.y, A.poses[pi], A.std_devs[vi]);
+            const Scene sc = park_scene(make_scene(A.robot_w, A.robot_h, row.x, row.y, A.poses[pi], A.std_devs[vi]), s_queue[wave]);
             uint32_t k = 0, n = 0;
             float p = 0.0f;
             bool done = false;
             for (uint32_t b = 0; b < A.burst_steps && !done; b++) {
-                k += wave_count_hits(sc, A.seed, A.scene_id_base + g, (uint64_t)n, n_batch, s_queue[wave]);
+                k += wave_count_hits<true>(sc, A.seed, A.scene_id_base + g, (uint64_t)n, n_batch, s_queue[wave]);
                 n += n_batch;
                 const float slack = calc_slack(n, k);                                       // ccp.cu:140
                 p = (float)k / (float)n;                                                    // ccp.cu:142
@@ -763,8 +948,8 @@ __global__ __launch_bounds__(kMcBlock, C2D_MC_ADV_WAVES) void mc_scenes_advance_
         vi = vi < A.num_std_devs ? vi : A.num_std_devs - 1;
         const Pose pose = A.poses[pi];
         const StdDev sd = A.std_devs[vi];
-        const Scene sc = make_scene(A.robot_w, A.robot_h, row.x, row.y, pose, sd);
-        const uint32_t h = wave_count_hits(sc, A.seed, A.scene_id_base + g, (uint64_t)n_start + off, count, s_queue[wave]);
+        const Scene sc = park_scene(make_scene(A.robot_w, A.robot_h, row.x, row.y, pose, sd), s_queue[wave]);
+        const uint32_t h = wave_count_hits<true>(sc, A.seed, A.scene_id_base + g, (uint64_t)n_start + off, count, s_queue[wave]);
         if ((threadIdx.x & 63) == 0 && h) atomicAdd(&A.hits[g], h);
     }
 }

@@ -327,3 +327,27 @@ def test_mc_scenes_with_non_finite_table_entries(eng, oracle, wl, pkg):
     hits, used, rows, total, _ = run_scenes(eng, pkg, poses, sds, scenes, 25000, 5, base=700)
     assert np.array_equal(used, ref_u) and np.array_equal(hits, ref_h) and total == ref_total
     assert np.array_equal(rows.view(np.uint32), ref_rows.view(np.uint32))
+
+
+@pytest.mark.parametrize("pos,pose,sd", [
+    ((3.035, 0.0), (2.0, 1.0, 0.0), (1e-6, 1e-6, 0.0, 0.0, 0.0)),       # edges touch along x (|gap| ~ 1e-6): overlaps on robot axis 0 are a few ulps
+    ((3.035, 0.0), (2.0, 1.0, 0.0), (1e-7, 0.0, 1e-7, 0.0, 0.0)),       # the same with a trembling angle
+    ((0.5, 1.37), (2.0, 1.0, 0.0), (0.0, 1e-6, 0.0, 0.0, 0.0)),         # touching along y
+    ((0.5, 1.37), (2.0, 1.0, 0.0), (0.3, 3e-7, 0.0, 0.0, 0.0)),
+    ((3.0541454553603, 0.5), (2.0, 1.0, 0.7853982), (2e-7, 2e-7, 0.0, 0.0, 0.0)),   # the same, an order of magnitude closer
+    ((3.035, 0.0), (2.0, 1.0, 0.0), (1e-5, 1e-5, 1e-5, 1e-5, 1e-5)),    # shape noise too
+    ((3.0, 1.0), (2.0, 1.0, 0.3), (300.0, 300.0, 0.3, 0.0, 0.0)),        # large coordinates: the certificates ask for wide overlaps
+    ((3.0541454553603, 0.5), (2.0, 1.0, 0.7853982), (1e-6, 1e-6, 1e-6, 0.0, 0.0)),   # a corner of the robot (at 45 degrees) grazing the obstacle
+    ((3.035, 0.0), (0.0, 0.0, 0.0), (1.0, 1.0, 0.5, 0.0, 0.0)),         # point obstacle: every obstacle axis is (0, 0)
+    ((1e-20, 1e-20), (1e-19, 1e-19, 0.3), (1e-20, 1e-20, 0.2, 0.0, 0.0)),  # everything tiny: products underflow
+])
+def test_mc_parallel_axis_certificates_on_razor_thin_overlaps(eng, oracle, pos, pose, sd):
+    """sample_collides_mask leaves out the second axis of each parallel pair when the overlap on the first is provably wide
+    enough (c2d_mc.hip).  Scenes whose overlaps sit within a few ulps of zero force the full evaluation of those axes; the hit
+    counts stay the oracle's, for the robot at the origin (exactly opposite edge axes) and rotated (rounded ones)."""
+    for robot_theta_pos in (pos, (pos[0] * 0.8 - pos[1] * 0.6, pos[0] * 0.6 + pos[1] * 0.8)):
+        for begin, n in ((0, 40_000), (777, 3_333)):
+            d = eng.zeros(1, np.uint64)
+            eng.mc_pair(W, H, robot_theta_pos, pose, sd, 21, 3, begin, n, d)
+            assert int(d.get()[0]) == oracle.mc_pair(W, H, robot_theta_pos, pose, sd, 21, 3, begin, n), (robot_theta_pos, begin)
+            d.free()
