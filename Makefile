@@ -32,7 +32,7 @@ CXX    ?= g++
 drivers: $(BINDIR)/generate_dataset $(BINDIR)/compute_collision_probability $(BINDIR)/ztest
 $(BINDIR)/%: $(HOST)/%.cpp $(HOST)/driver_common.hpp $(HOST)/npy.hpp $(HOST)/cli.hpp include/c2d.h include/utils.h $(LIBDIR)/libc2d.so
 	@mkdir -p $(BINDIR)
-	$(CXX) -O2 -std=c++17 -Wall -Wextra $< -o $@ -L$(LIBDIR) -lc2d -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath-link,/opt/rocm/lib
+	$(CXX) -O2 -std=c++17 -pthread -Wall -Wextra $< -o $@ -L$(LIBDIR) -lc2d -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath-link,/opt/rocm/lib
 
 clean:
 	rm -f $(OBJS) $(LIBDIR)/libc2d.so $(BINDIR)/generate_dataset $(BINDIR)/compute_collision_probability $(BINDIR)/ztest

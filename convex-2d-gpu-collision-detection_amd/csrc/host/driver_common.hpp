@@ -12,6 +12,7 @@
 #include <iostream>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/c2d.h"
@@ -195,6 +196,71 @@ struct BatchSlot {
     }
 };
 
+// ---- the reference's tables, drawn in parallel ---------------------------------------------------------------------
+// generate_dataset.cu:279-332 fills the variance and pose tables from ONE std::default_random_engine (minstd_rand0:
+// x <- 16807 x mod 2^31 - 1, default seed 1), row by row, dimension by dimension; uniform_real_distribution<float> takes
+// one engine call per float (generate_canonical<float, 24> needs 24 bits, the engine delivers ~31).  That engine can jump:
+// the state after k calls is 16807^k x mod (2^31 - 1).  Thread t therefore starts its slice of the table from the state
+// the serial loop would have there and draws the same floats — the 64^4-row default tables (134 M draws) in 1/T of the
+// serial 0.63 s.  The one-call-per-float property is libstdc++'s, not the standard's, so it is checked against a short
+// serial run first; if it does not hold the table is drawn serially.
+inline uint64_t minstd_power(uint64_t k)
+{
+    const uint64_t m = 2147483647ull;
+    uint64_t result = 1, base = 16807;
+    for (; k; k >>= 1) {
+        if (k & 1) result = result * base % m;
+        base = base * base % m;
+    }
+    return result;
+}
+
+// rows x dims floats, dimension d uniform in [lo[d], hi[d]); first_draw = engine calls made before this table
+inline void fill_uniform_table_serial(float* out, size_t rows, int dims, const float* lo, const float* hi, std::minstd_rand0& gen)
+{
+    std::vector<std::uniform_real_distribution<float>> u;
+    for (int d = 0; d < dims; d++) u.emplace_back(lo[d], hi[d]);
+    for (size_t i = 0; i < rows; i++)
+        for (int d = 0; d < dims; d++) out[i * dims + d] = u[d](gen);
+}
+
+inline bool fill_uniform_table(float* out, size_t rows, int dims, const float* lo, const float* hi, uint64_t first_draw, unsigned threads)
+{
+    auto engine_at = [](uint64_t calls) {
+        std::minstd_rand0 e;  // default seed 1
+        e.seed(static_cast<std::minstd_rand0::result_type>(minstd_power(calls)));
+        return e;
+    };
+    // does a jumped engine continue the serial sequence on this standard library?  (one engine call per float)
+    {
+        const size_t probe = 64;
+        std::vector<float> a(probe * dims), b(probe * dims);
+        std::minstd_rand0 serial = engine_at(0);
+        fill_uniform_table_serial(a.data(), probe, dims, lo, hi, serial);
+        std::minstd_rand0 j0 = engine_at(0), j1 = engine_at(probe / 2 * dims);
+        fill_uniform_table_serial(b.data(), probe / 2, dims, lo, hi, j0);
+        fill_uniform_table_serial(b.data() + probe / 2 * dims, probe / 2, dims, lo, hi, j1);
+        if (a != b) threads = 1;
+    }
+    if (threads <= 1 || rows < 4096) {
+        std::minstd_rand0 e = engine_at(first_draw);
+        fill_uniform_table_serial(out, rows, dims, lo, hi, e);
+        return threads > 1;
+    }
+    std::vector<std::thread> pool;
+    const size_t per = (rows + threads - 1) / threads;
+    for (unsigned t = 0; t < threads; t++) {
+        const size_t b = t * per, e = b + per < rows ? b + per : rows;
+        if (b >= e) break;
+        pool.emplace_back([=]() {
+            std::minstd_rand0 eng = engine_at(first_draw + b * dims);
+            fill_uniform_table_serial(out + b * dims, e - b, dims, lo, hi, eng);
+        });
+    }
+    for (auto& th : pool) th.join();
+    return true;
+}
+
 inline std::vector<StdDev> std_devs_from_variances(const std::vector<float>& var_flat)
 {
     // element-wise sqrt (generate_dataset.cu:309-317, compute_collision_probability.cu:188-194)
@@ -208,6 +274,29 @@ inline std::vector<StdDev> std_devs_from_variances(const std::vector<float>& var
     }
     return sd;
 }
+
+// wall-clock split of a run, printed in the JSON summary (rank 0's own phases)
+struct PhaseClock {
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    std::vector<std::pair<std::string, double>> phases;
+    void lap(const char* name)
+    {
+        const auto now = std::chrono::steady_clock::now();
+        phases.emplace_back(name, std::chrono::duration<double>(now - t).count());
+        t = now;
+    }
+    void add(const char* name, double seconds) { phases.emplace_back(name, seconds); }
+    std::string json() const
+    {
+        std::string s = ", \"phases_s\": {";
+        char buf[96];
+        for (size_t i = 0; i < phases.size(); i++) {
+            std::snprintf(buf, sizeof buf, "%s\"%s\": %.4f", i ? ", " : "", phases[i].first.c_str(), phases[i].second);
+            s += buf;
+        }
+        return s + "}";
+    }
+};
 
 struct RunStats {
     // histogram of cp over the bins of the reference's dataset tooling (balance_datasets.py:15-20, :36:
@@ -231,7 +320,8 @@ struct RunStats {
 
 // One line per run.  With an aggregation link it is printed by rank 0 only and holds the sums over all ranks
 // (samples, hits, scenes, batches, the cp histogram; seconds = the slowest rank's).
-inline int print_json_summary(const char* tool, const Shard& sh, RunStats st, int batches, DistLink* link, c2d_stream stream)
+inline int print_json_summary(const char* tool, const Shard& sh, RunStats st, int batches, DistLink* link, c2d_stream stream,
+                              const std::string& extra_json = "")
 {
     const char* reduce = "none";
     int ranks = 1;
@@ -257,10 +347,10 @@ inline int print_json_summary(const char* tool, const Shard& sh, RunStats st, in
     }
     std::printf("{\"tool\": \"%s\", \"rank\": %d, \"world_size\": %d, \"aggregated_over_ranks\": %d, \"reduce\": \"%s\", \"batches\": %d, "
                 "\"scenes\": %llu, \"mc_samples\": %llu, \"hits\": %llu, \"pooled_probability\": %.9g, "
-                "\"seconds\": %.3f, \"mc_samples_per_s\": %.4g, \"cp_hist_bins\": [0, 0.001, 0.01, 0.1, 1], \"cp_hist\": [%llu, %llu, %llu, %llu]}\n",
+                "\"seconds\": %.3f, \"mc_samples_per_s\": %.4g, \"cp_hist_bins\": [0, 0.001, 0.01, 0.1, 1], \"cp_hist\": [%llu, %llu, %llu, %llu]%s}\n",
                 tool, sh.rank, sh.world, ranks, reduce, batches, st.scenes, st.samples, st.hits,
                 st.samples ? static_cast<double>(st.hits) / static_cast<double>(st.samples) : 0.0, st.seconds,
-                st.seconds > 0 ? st.samples / st.seconds : 0.0, st.cp_hist[0], st.cp_hist[1], st.cp_hist[2], st.cp_hist[3]);
+                st.seconds > 0 ? st.samples / st.seconds : 0.0, st.cp_hist[0], st.cp_hist[1], st.cp_hist[2], st.cp_hist[3], extra_json.c_str());
     std::fflush(stdout);
     return C2D_OK;
 }

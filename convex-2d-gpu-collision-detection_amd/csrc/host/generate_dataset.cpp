@@ -135,19 +135,25 @@ int main(int argc, char* argv[])
     // (generate_dataset.cu:279-332): std::default_random_engine, default seeded, all variances
     // first, then all poses — so a libstdc++ build reproduces the reference's tables.
     std::vector<float> variances, poses;  // flat [Nv][5], [Np][3]
-    std::default_random_engine generator;
+    uint64_t draws = 0;  // engine calls so far (the serial std::default_random_engine of the reference, drawn in parallel: driver_common.hpp)
+    const unsigned table_threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    PhaseClock clock;
+    double table_file_s = 0.0;
+    auto timed_save = [&](const std::string& path, std::vector<size_t> shape, const float* data) {
+        const auto t0 = std::chrono::steady_clock::now();
+        npy::save_f32(path, shape, data);
+        table_file_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    };
     try {
         if (a.variance_dir.empty()) {
             if (!a.shape_variance) {
                 a.min_variance[3] = a.max_variance[3] = 0.0f;
                 a.min_variance[4] = a.max_variance[4] = 0.0f;
             }
-            std::vector<std::uniform_real_distribution<float>> u;
-            for (int i = 0; i < 5; i++) u.emplace_back(a.min_variance[i], a.max_variance[i]);
             variances.resize(static_cast<size_t>(a.num_variances) * 5);
-            for (int i = 0; i < a.num_variances; i++)
-                for (int d = 0; d < 5; d++) variances[static_cast<size_t>(i) * 5 + d] = u[d](generator);
-            if (shard.rank == 0) npy::save_f32(data_dir + "/variances.npy", {static_cast<size_t>(a.num_variances), 5}, variances.data());
+            fill_uniform_table(variances.data(), static_cast<size_t>(a.num_variances), 5, a.min_variance.data(), a.max_variance.data(), draws, table_threads);
+            draws += static_cast<uint64_t>(a.num_variances) * 5;
+            if (shard.rank == 0) timed_save(data_dir + "/variances.npy", {static_cast<size_t>(a.num_variances), 5}, variances.data());
         } else {
             npy::Array v = npy::load_f32(a.variance_dir);
             if (v.data.size() % 5) throw std::runtime_error("variances file is not [N,5]");
@@ -155,12 +161,10 @@ int main(int argc, char* argv[])
             a.num_variances = static_cast<int>(variances.size() / 5);
         }
         if (a.pose_dir.empty()) {
-            std::vector<std::uniform_real_distribution<float>> u;
-            for (int i = 0; i < 3; i++) u.emplace_back(a.min_pose[i], a.max_pose[i]);
             poses.resize(static_cast<size_t>(a.num_poses) * 3);
-            for (int i = 0; i < a.num_poses; i++)
-                for (int d = 0; d < 3; d++) poses[static_cast<size_t>(i) * 3 + d] = u[d](generator);
-            if (shard.rank == 0) npy::save_f32(data_dir + "/poses.npy", {static_cast<size_t>(a.num_poses), 3}, poses.data());
+            fill_uniform_table(poses.data(), static_cast<size_t>(a.num_poses), 3, a.min_pose.data(), a.max_pose.data(), draws, table_threads);
+            draws += static_cast<uint64_t>(a.num_poses) * 3;
+            if (shard.rank == 0) timed_save(data_dir + "/poses.npy", {static_cast<size_t>(a.num_poses), 3}, poses.data());
         } else {
             npy::Array v = npy::load_f32(a.pose_dir);
             if (v.data.size() % 3) throw std::runtime_error("poses file is not [N,3]");
@@ -177,6 +181,10 @@ int main(int argc, char* argv[])
     }
     if (a.num_poses <= 0 || a.num_variances <= 0) { std::cerr << "error: empty pose / variance table\n"; return EXIT_FAILURE; }
     std::vector<StdDev> std_devs = std_devs_from_variances(variances);
+    clock.lap("tables_generate_and_save");
+    clock.phases.back().second -= table_file_s;
+    clock.phases.back().first = "tables_generate";
+    clock.add("tables_save_npy", table_file_s);
     if (chatty) {
         std::cout << "num poses: " << a.num_poses << std::endl;
         std::cout << "num variances: " << a.num_variances << std::endl;
@@ -201,6 +209,8 @@ int main(int argc, char* argv[])
     C2D_CALL(ctx, c2d_memcpy_h2d(ctx, d_poses, poses.data(), poses.size() * sizeof(float), stream));
     C2D_CALL(ctx, c2d_memcpy_h2d(ctx, d_sd, std_devs.data(), std_devs.size() * sizeof(StdDev), stream));
     C2D_CALL(ctx, c2d_stream_synchronize(ctx, stream));
+    clock.lap("device_open_and_table_upload");
+    double wait_gpu_s = 0.0, host_batch_s = 0.0;  // inside the batch loop: waiting for a batch's stream / statistics + shuffle + file
 
     const auto begin = std::chrono::steady_clock::now();
     if (chatty) {
@@ -237,7 +247,10 @@ int main(int argc, char* argv[])
     };
     // the host side of a batch: wait for its stream, statistics, shuffle, file
     auto finish = [&](BatchSlot& sl) -> int {
+        const auto w0 = std::chrono::steady_clock::now();
         int st = c2d_stream_synchronize(sl.ctx, sl.stream);
+        const auto w1 = std::chrono::steady_clock::now();
+        wait_gpu_s += std::chrono::duration<double>(w1 - w0).count();
         if (st != C2D_OK) return st;
         stats.scenes += B;
         for (size_t i = 0; i < B; i++) stats.samples += sl.used[i];
@@ -248,6 +261,7 @@ int main(int argc, char* argv[])
                       reinterpret_cast<const float*>(sl.dataset));  // :499-500
         sl.batch_index = -1;
         const auto now = std::chrono::steady_clock::now();
+        host_batch_s += std::chrono::duration<double>(now - w1).count();
         ++counter;
         if (chatty) {
             std::printf("\33[2K\r");
@@ -277,7 +291,10 @@ int main(int argc, char* argv[])
         std::cout << "Finished computation" << std::endl;
         std::cout << "Elapsed time: " << std::chrono::duration_cast<std::chrono::minutes>(end - begin).count() << " [min]" << std::endl;
     }
-    C2D_CALL(ctx, print_json_summary("generate_dataset", shard, stats, counter, &link, stream));
+    clock.lap("batches");
+    clock.add("batches_waiting_for_gpu", wait_gpu_s);
+    clock.add("batches_host_stats_shuffle_npy", host_batch_s);
+    C2D_CALL(ctx, print_json_summary("generate_dataset", shard, stats, counter, &link, stream, clock.json()));
     for (void* ptr : {d_poses, d_sd}) c2d_free(ctx, ptr);
     link.close();
     for (auto& sl : slots) sl.close();

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_host_helpers(tmp_path):
     exe = tmp_path / "test_host_helpers"
-    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-I" + os.path.join(ROOT, "convex-2d-gpu-collision-detection_amd", "csrc", "host"),
+    subprocess.run(["g++", "-std=c++17", "-O1", "-pthread", "-Wall", "-Wextra", "-I" + os.path.join(ROOT, "convex-2d-gpu-collision-detection_amd", "csrc", "host"),
                     os.path.join(ROOT, "tests", "cpp", "test_host_helpers.cpp"), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe), str(tmp_path)], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
