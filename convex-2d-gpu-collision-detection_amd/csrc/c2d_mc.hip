@@ -452,6 +452,16 @@ C2D_DEV Scene load_eval(const Scene& hot, const WaveQueue& q)
     return sc;
 }
 
+#ifndef C2D_MC_PARK_ADAPTIVE
+#define C2D_MC_PARK_ADAPTIVE 1  // 0: the adaptive kernels keep the whole scene in registers too (the A/B of profiles/r03_mc_isa.md)
+#endif
+constexpr bool kParkAdaptive = C2D_MC_PARK_ADAPTIVE != 0;
+C2D_DEV Scene adaptive_scene(const Scene& sc, WaveQueue& q)
+{
+    if constexpr (kParkAdaptive) return park_scene(sc, q);
+    else return sc;
+}
+
 // ---- NEAR: hits among samples [begin, begin + count) of one scene, computed by one wave.  A lane owns one GROUP of four
 // samples per iteration (draw layout: c2d_math.hpp), so an iteration covers 256 consecutive samples; sub-iteration
 // j = 0..3 handles member j of the 64 groups.  begin and count are arbitrary (a shard may start inside a group):
@@ -907,12 +917,12 @@ __global__ __launch_bounds__(kMcBlock, C2D_MC_ADV_WAVES) void mc_scenes_advance_
             uint32_t pi = (uint32_t)(int)row.pose_idx, vi = (uint32_t)(int)row.var_idx;
             pi = pi < A.num_poses ? pi : A.num_poses - 1;
             vi = vi < A.num_std_devs ? vi : A.num_std_devs - 1;
-            const Scene sc = park_scene(make_scene(A.robot_w, A.robot_h, row.x, row.y, A.poses[pi], A.std_devs[vi]), s_queue[wave]);
+            const Scene sc = adaptive_scene(make_scene(A.robot_w, A.robot_h, row.x, row.y, A.poses[pi], A.std_devs[vi]), s_queue[wave]);
             uint32_t k = 0, n = 0;
             float p = 0.0f;
             bool done = false;
             for (uint32_t b = 0; b < A.burst_steps && !done; b++) {
-                k += wave_count_hits<true>(sc, A.seed, A.scene_id_base + g, (uint64_t)n, n_batch, s_queue[wave]);
+                k += wave_count_hits<kParkAdaptive>(sc, A.seed, A.scene_id_base + g, (uint64_t)n, n_batch, s_queue[wave]);
                 n += n_batch;
                 const float slack = calc_slack(n, k);                                       // ccp.cu:140
                 p = (float)k / (float)n;                                                    // ccp.cu:142
@@ -948,8 +958,8 @@ __global__ __launch_bounds__(kMcBlock, C2D_MC_ADV_WAVES) void mc_scenes_advance_
         vi = vi < A.num_std_devs ? vi : A.num_std_devs - 1;
         const Pose pose = A.poses[pi];
         const StdDev sd = A.std_devs[vi];
-        const Scene sc = park_scene(make_scene(A.robot_w, A.robot_h, row.x, row.y, pose, sd), s_queue[wave]);
-        const uint32_t h = wave_count_hits<true>(sc, A.seed, A.scene_id_base + g, (uint64_t)n_start + off, count, s_queue[wave]);
+        const Scene sc = adaptive_scene(make_scene(A.robot_w, A.robot_h, row.x, row.y, pose, sd), s_queue[wave]);
+        const uint32_t h = wave_count_hits<kParkAdaptive>(sc, A.seed, A.scene_id_base + g, (uint64_t)n_start + off, count, s_queue[wave]);
         if ((threadIdx.x & 63) == 0 && h) atomicAdd(&A.hits[g], h);
     }
 }
