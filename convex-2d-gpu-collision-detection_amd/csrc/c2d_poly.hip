@@ -319,6 +319,10 @@ __global__ __launch_bounds__(64) void sat_poly4_kernel(const float* __restrict__
     if (d_count) wave_count_arrive(my_count, d_count, words);
 }
 
+// c2d_poly_binned.hip: a padded layout run as ONE bin of the binned kernel (its 12- and 16-row instances)
+int launch_poly_onebin(hipStream_t s, const float* d_vx, const float* d_vy, const uint8_t* d_k, size_t n, int rows, uint8_t* d_out,
+                       unsigned long long* d_count, unsigned long long* words2, uint32_t* async_err);
+
 template <int KM, int MIN_WAVES, bool FULL>
 static void launch_poly(hipStream_t s, const float* d_vx, const float* d_vy, const uint8_t* d_k, size_t n, int rows, uint8_t* d_out,
                         unsigned long long* d_count, unsigned long long* words, uint32_t* async_err)
@@ -354,7 +358,12 @@ int c2d_sat_poly_pairs_rows(c2d_ctx* ctx, const float* d_vx, const float* d_vy, 
         hipLaunchKernelGGL(sat_poly4_kernel, dim3((unsigned)(blocks < (size_t)kMaxGrid ? blocks : (size_t)kMaxGrid)), dim3(64), 0, s, d_vx, d_vy, d_k, n,
                            n_groups, d_out, d_count, words, err);
     } else if (rows == 16) launch_poly<16, 5, true>(s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words2, err);
-    else if (rows > 8) launch_poly<16, 5, false>(s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words2, err);
+    else if (rows > 8) {
+        // 9..15 rows: the binned kernel's 12- / 16-row instances with the layout as ONE bin (all rows requested at once, straight-line
+        // phase 1: 12-row layouts 0.330 instead of 0.368 ms per 1e7 pairs); planes of 4 GiB and more stay with the generic instance
+        if (launch_poly_onebin(s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words2, err) != C2D_OK)
+            launch_poly<16, 5, false>(s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words2, err);
+    }
     else if (rows > 4) launch_poly<8, 7, false>(s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words2, err);
     else launch_poly<4, 8, false>(s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words2, err);
     C2D_LAUNCH_CHECK(ctx);

@@ -68,8 +68,8 @@ C2D_DEV float plane_load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
 // never separates, a repeated projection changes no extreme), so only the LOADS of the last three rows are guarded.
 // Returns "separated by the one axis tested"; the vertices stay in ax .. by for the parking step of phase 2.
 template <int CA, int CB>
-C2D_DEV bool binned_phase1(const BinDesc& D, uint32_t p0, uint32_t cl, bool& bad, float (&ax)[C2D_POLY_KMAX], float (&ay)[C2D_POLY_KMAX],
-                           float (&bx)[C2D_POLY_KMAX], float (&by)[C2D_POLY_KMAX], uint32_t* __restrict__ async_err)
+C2D_DEV bool binned_phase1(const BinDesc& D, uint32_t p0, uint32_t cl, bool& bad, int& ka, int& kb, float (&ax)[C2D_POLY_KMAX],
+                           float (&ay)[C2D_POLY_KMAX], float (&bx)[C2D_POLY_KMAX], float (&by)[C2D_POLY_KMAX], uint32_t* __restrict__ async_err)
 {
     const int rows_a = D.rows_a, rows_b = D.rows_b;
     const uint32_t row_bytes = D.stride * 4u;
@@ -104,7 +104,8 @@ C2D_DEV bool binned_phase1(const BinDesc& D, uint32_t p0, uint32_t cl, bool& bad
             soff += row_bytes;
         }
     }
-    int ka = rows_a, kb = rows_b;  // (per lane; wave-uniform in a bin without count arrays)
+    ka = rows_a;  // (per lane; wave-uniform in a bin without count arrays)
+    kb = rows_b;
     bad = false;
     if (D.ka != nullptr) {
         ka = D.ka[p0 + cl];
@@ -185,18 +186,17 @@ C2D_DEV void binned_park(float2* slot, const float (&ax)[C2D_POLY_KMAX], const f
 #define C2D_BIN_VARIANTS(X) X(4, 4) X(8, 4) X(8, 8) X(12, 4) X(12, 8) X(12, 12) X(16, 4) X(16, 8) X(16, 12) X(16, 16)
 C2D_DEV int bin_variant(int rows_a, int rows_b) { return ((rows_a + 3) >> 2) * 4 + ((rows_b + 3) >> 2); }   // ca4 * 4 + cb4, ca4 >= cb4 >= 1
 
-__global__ __launch_bounds__(64, 5) void sat_poly_binned_kernel(const BinDesc* __restrict__ bins, const uint32_t* __restrict__ tile_bin,
-                                                               uint32_t tile_offset, unsigned long long* __restrict__ d_count,
-                                                               unsigned long long* __restrict__ words, uint32_t* __restrict__ async_err)
+// One tile (64 pairs) of one bin.  SYM: only the instances with equal row classes on both sides are compiled (the padded
+// layouts of c2d_sat_poly_pairs_rows are one bin with rows_a == rows_b).
+template <bool SYM>
+C2D_DEV void binned_tile(const BinDesc& D, uint32_t tile_in_bin, unsigned long long* __restrict__ d_count, unsigned long long* __restrict__ words,
+                         uint32_t* __restrict__ async_err)
 {
     constexpr int KM = C2D_POLY_KMAX;
     __shared__ __attribute__((aligned(16))) float2 s_slot[kBinSlots][kSlotF2];
     const uint32_t lane = threadIdx.x;
-    const uint32_t tile = blockIdx.x + tile_offset;
-    const uint32_t bin = __builtin_amdgcn_readfirstlane(tile_bin[tile]);
-    const BinDesc D = bins[bin];
     const int rows_a = D.rows_a, rows_b = D.rows_b;
-    const uint32_t p0 = (tile - D.tile0) * 64u;
+    const uint32_t p0 = tile_in_bin * 64u;
     const uint32_t here = (D.n - p0) < 64u ? (D.n - p0) : 64u;  // wave-uniform
     const bool in = lane < here;
     const uint32_t cl = in ? lane : here - 1;  // lanes past the end re-read the last pair (never stored)
@@ -204,8 +204,10 @@ __global__ __launch_bounds__(64, 5) void sat_poly_binned_kernel(const BinDesc* _
     // ---- phase 1: one axis of A per pair, everything in registers ------------------------------------------------------
     float ax[KM], ay[KM], bx[KM], by[KM];
     bool sep = false, bad = false;
+    int ka = 0, kb = 0;
+    const bool counted = D.ka != nullptr;  // wave-uniform
     switch (variant) {
-#define C2D_BIN_CASE(CA, CB) case (CA / 4) * 4 + CB / 4: sep = binned_phase1<CA, CB>(D, p0, cl, bad, ax, ay, bx, by, async_err); break;
+#define C2D_BIN_CASE(CA, CB) case (CA / 4) * 4 + CB / 4: if constexpr (!SYM || CA == CB) sep = binned_phase1<CA, CB>(D, p0, cl, bad, ka, kb, ax, ay, bx, by, async_err); break;
         C2D_BIN_VARIANTS(C2D_BIN_CASE)
 #undef C2D_BIN_CASE
     default: break;
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(64, 5) void sat_poly_binned_kernel(const BinDesc* _
             if (park) {
                 float2* slot = &s_slot[rank][0];
                 switch (variant) {
-#define C2D_BIN_CASE(CA, CB) case (CA / 4) * 4 + CB / 4: binned_park<CA, CB>(slot, ax, ay, bx, by); break;
+#define C2D_BIN_CASE(CA, CB) case (CA / 4) * 4 + CB / 4: if constexpr (!SYM || CA == CB) binned_park<CA, CB>(slot, ax, ay, bx, by); break;
                     C2D_BIN_VARIANTS(C2D_BIN_CASE)
 #undef C2D_BIN_CASE
                 default: break;
@@ -257,12 +259,29 @@ __global__ __launch_bounds__(64, 5) void sat_poly_binned_kernel(const BinDesc* _
                 const float nx = -(e1.y - e0.y), ny = e1.x - e0.x;
                 float mn1 = __builtin_inff(), mx1 = -__builtin_inff(), mn2 = __builtin_inff(), mx2 = -__builtin_inff();
                 // slots past a polygon's count repeat its vertex 0, so the scans need no masking
-                for (int r2 = 0; r2 < ra2; r2++) {
+                // In a bin that holds several sizes the scans stop at the largest count among the trip's pairs (slots above a
+                // polygon's own count repeat its vertex 0, so a longer scan is harmless).  (A one-read-ahead form of these loops
+                // was measured: 5 more VGPRs, 0.264 -> 0.279 ms on the bench bins, nothing gained on dense scenes.)
+                int na2 = ra2, nb2 = rb2;
+                if (counted && LP > 16) {  // (small bins: the bound costs more than the few iterations it saves)
+                    unsigned long long t2 = todo;
+                    int kA = 0, kB = 0;
+                    for (int q = 0; q < cnt; q++) {
+                        const int j = __ffsll((long long)t2) - 1;
+                        t2 &= t2 - 1;
+                        const int kaq = __builtin_amdgcn_readlane(ka, j), kbq = __builtin_amdgcn_readlane(kb, j);
+                        kA = kaq > kA ? kaq : kA;
+                        kB = kbq > kB ? kbq : kB;
+                    }
+                    na2 = (kA + 1) >> 1;
+                    nb2 = (kB + 1) >> 1;
+                }
+                for (int r2 = 0; r2 < na2; r2++) {
                     const float4 q4 = SA[r2];
                     binned_minmax(nx, ny, q4.x, q4.y, mn1, mx1);
                     binned_minmax(nx, ny, q4.z, q4.w, mn1, mx1);
                 }
-                for (int r2 = 0; r2 < rb2; r2++) {
+                for (int r2 = 0; r2 < nb2; r2++) {
                     const float4 q4 = SB[r2];
                     binned_minmax(nx, ny, q4.x, q4.y, mn2, mx2);
                     binned_minmax(nx, ny, q4.z, q4.w, mn2, mx2);
@@ -284,6 +303,41 @@ __global__ __launch_bounds__(64, 5) void sat_poly_binned_kernel(const BinDesc* _
     if (d_count) wave_count_arrive_total2((uint32_t)__popcll(__ballot(collide)), d_count, words);
 }
 static_assert(kCountWords2Bytes == C2D_COUNT_WORDS2_BYTES, "workspace size of the two-level count");
+
+// every bin of a batch in one launch: a u32 per tile names the bin
+__global__ __launch_bounds__(64, 5) void sat_poly_binned_kernel(const BinDesc* __restrict__ bins, const uint32_t* __restrict__ tile_bin,
+                                                               uint32_t tile_offset, unsigned long long* __restrict__ d_count,
+                                                               unsigned long long* __restrict__ words, uint32_t* __restrict__ async_err)
+{
+    const uint32_t tile = blockIdx.x + tile_offset;
+    const uint32_t bin = __builtin_amdgcn_readfirstlane(tile_bin[tile]);
+    const BinDesc D = bins[bin];
+    binned_tile<false>(D, tile - D.tile0, d_count, words, async_err);
+}
+
+// ONE bin whose descriptor travels in the kernel arguments: the padded layouts of c2d_sat_poly_pairs_rows (no table, no upload)
+__global__ __launch_bounds__(64, 5) void sat_poly_onebin_kernel(BinDesc D, uint32_t tile_offset, unsigned long long* __restrict__ d_count,
+                                                               unsigned long long* __restrict__ words, uint32_t* __restrict__ async_err)
+{
+    binned_tile<true>(D, blockIdx.x + tile_offset, d_count, words, async_err);
+}
+
+// host entry used by c2d_poly.hip: rows_a == rows_b == rows, planes rows * n apart
+int launch_poly_onebin(hipStream_t s, const float* d_vx, const float* d_vy, const uint8_t* d_k, size_t n, int rows, uint8_t* d_out,
+                       unsigned long long* d_count, unsigned long long* words2, uint32_t* async_err)
+{
+    if (n > 0xffffffffull || (uint64_t)rows * n * 4 > 0xffffffffull) return C2D_ERR_UNSUPPORTED;
+    BinDesc D;
+    D.ax = d_vx; D.ay = d_vy; D.bx = d_vx + (size_t)rows * n; D.by = d_vy + (size_t)rows * n;
+    D.ka = d_k; D.kb = d_k + n; D.out = d_out;
+    D.n = (uint32_t)n; D.stride = (uint32_t)n; D.tile0 = 0; D.rows_a = (uint16_t)rows; D.rows_b = (uint16_t)rows;
+    const size_t tiles = (n + 63) / 64;
+    for (size_t t0 = 0; t0 < tiles; t0 += (size_t)kMaxGrid) {
+        const size_t grid = std::min(tiles - t0, (size_t)kMaxGrid);
+        hipLaunchKernelGGL(sat_poly_onebin_kernel, dim3((unsigned)grid), dim3(64), 0, s, D, (uint32_t)t0, d_count, words2, async_err);
+    }
+    return C2D_OK;
+}
 
 // ---- binning a padded batch -------------------------------------------------------------------------------------------
 // class of a pair: (ceil(ka / g) - 1) * 16 + (ceil(kb / g) - 1); counts outside 1..rows go to class 255 = "bad" which is
