@@ -258,3 +258,37 @@ def test_rehearsal_transport_lives_in_its_own_build(eng, pkg):
     with pytest.raises(pkg.C2DError):
         e2.dist_init(0, 1, eng.dist_unique_id())   # an RCCL id is not a rehearsal id
     e2.close()
+
+
+def _visible_gpus():
+    out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
+    try:
+        return int(out.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        return 0
+
+
+def test_rccl_with_two_real_ranks_when_two_gpus_are_visible(tmp_path):
+    """The product path with N > 1: two ranks on two devices, ncclCommInitRank + ncclAllReduce over xGMI through libc2d — bench.py
+    starting its own ranks and the drivers' --gpus 2.  Needs two GPUs: skipped on the one-GPU test box, runs wherever the suite is
+    started on a multi-GPU node."""
+    if _visible_gpus() < 2:
+        pytest.skip("needs two visible GPUs (RCCL refuses two ranks on one device)")
+    small = ["--steps", "3", "--warmup", "1", "--pairs", "1000000", "--mc-samples", "1000000", "--mc-reps", "1", "--scenes", "20000",
+             "--scenes-max-samples", "3000", "--poly-pairs", "200000", "--poly-reps", "2", "--no-cpu-baseline", "--prewarm-ms", "5"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + small, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = json.loads(out.stdout.strip().splitlines()[-1])
+    assert j["n_gpus"] == 2 and j["config"]["ranks_in_reduce"] == 2 and "rccl" in j["config"]["reduce"]
+    assert abs(j["mc"]["probability"] - 0.5537) < 5e-3
+    args = ["-n", "4", "-b", "900", "--num_poses", "200", "--num_variances", "100", "--max_samples", "3000", "--seed", "77"]
+    one = run([GEN, "--data_dir", str(tmp_path / "one")] + args)
+    two = run([GEN, "--data_dir", str(tmp_path / "two"), "--gpus", "2"] + args)
+    assert one.returncode == 0 and two.returncode == 0, one.stderr + two.stderr
+    s1, s2 = summary_of(one), summary_of(two)
+    assert s2["aggregated_over_ranks"] == 2 and s2["reduce"] == "rccl"
+    for key in ("batches", "scenes", "mc_samples", "hits", "cp_hist"):
+        assert s1[key] == s2[key], key
+    for k in range(4):
+        assert np.array_equal(np.load(tmp_path / "one" / f"{k}.npy").view(np.uint32), np.load(tmp_path / "two" / f"{k}.npy").view(np.uint32)), k
