@@ -430,49 +430,125 @@ struct BinMoveArgs {
     const BinDesc* table;          // one entry per bin, polygons as in the INPUT (not the test kernel's swapped view)
     const uint16_t* class_to_bin;  // [256], 0xffff = empty class
     const uint32_t* pair_base;     // [bins]: first position of the bin in the concatenated order
-    const uint32_t* block_prefix;  // [blocks][256] from the scan
+    const uint32_t* block_prefix;  // [blocks of 1024 pairs][256] from the scan
+    const uint32_t* totals;        // [256] pairs per class
+    uint32_t n_blocks;             // blocks of 1024 pairs
     uint32_t* index;               // [n] out: position of input pair i; 0xffffffff = bad counts
 };
 
+// The move: a block owns a TILE of 4096 consecutive pairs (four of the count pass's blocks).  Lanes that write one pair each
+// scatter 4-byte stores over as many cache lines as there are classes in a wave (196 bins: 7.5 ms per 1e7 pairs), so the tile
+// is first sorted by destination: every pair gets its slot (prefix of its 1024-block and class + pairs of the class in earlier
+// waves + rank in its wave, as before), the tile's pairs are ordered by (class, slot) in LDS, and then every vertex row of
+// every plane passes through an LDS stage — read from the padded batch as it lies (coalesced), written in destination order,
+// where neighbouring lanes hold neighbouring slots of one class.
+constexpr int kMoveTile = 4096, kMoveSub = kMoveTile / kBinBlock;
+
 __global__ __launch_bounds__(kBinBlock) void poly_bin_move_kernel(BinMoveArgs A)
 {
-    __shared__ uint16_t s_wc[kBinWaves][256];
-    for (int i = threadIdx.x; i < kBinWaves * 256; i += kBinBlock) (&s_wc[0][0])[i] = 0;
+    __shared__ float s_stage[2][kMoveTile];       // one vertex row of the tile, x and y
+    // per-wave class counts of the 1024-block in hand: only needed while the slots are computed, so they live in the stage
+    uint16_t (*s_wc)[256] = reinterpret_cast<uint16_t (*)[256]>(&s_stage[0][0]);
+    static_assert(sizeof(uint16_t) * kBinWaves * 256 <= sizeof(float) * kMoveTile, "s_wc fits the stage");
+    __shared__ uint32_t s_slot[kMoveTile];        // slot of local pair li within its bin
+    __shared__ uint16_t s_cls[kMoveTile];         // its class, 0xffff = bad counts
+    __shared__ uint16_t s_sorted[kMoveTile];      // local pair at position sp of the tile's (class, slot) order
+    __shared__ uint32_t s_cbase[257];             // first position of class c in that order; [256] = valid pairs of the tile
+    __shared__ uint32_t s_first[256];             // slot of the tile's first pair of class c
+    __shared__ float* s_plane[4][256];            // ax, ay, bx, by of the class's bin
+    __shared__ uint32_t s_stride[256];
+    __shared__ uint8_t s_rows[2][256];
+    const uint32_t t = threadIdx.x, wave = t >> 6;
+    const uint32_t blk0 = blockIdx.x * kMoveSub;  // first 1024-block of the tile
+    const size_t tile0 = (size_t)blockIdx.x * kMoveTile;
+    // ---- per-class tables of this tile
+    if (t < 256) {
+        const uint32_t c = t;
+        const uint32_t bin = A.class_to_bin[c];
+        uint32_t cnt = 0, first = 0;
+        if (bin != 0xffffu) {
+            const BinDesc D = A.table[bin];
+            s_plane[0][c] = const_cast<float*>(D.ax); s_plane[1][c] = const_cast<float*>(D.ay);
+            s_plane[2][c] = const_cast<float*>(D.bx); s_plane[3][c] = const_cast<float*>(D.by);
+            s_stride[c] = D.stride;
+            s_rows[0][c] = (uint8_t)D.rows_a; s_rows[1][c] = (uint8_t)D.rows_b;
+            first = A.block_prefix[(size_t)blk0 * 256 + c];
+            const uint32_t next_blk = blk0 + kMoveSub;
+            const uint32_t end = next_blk < A.n_blocks ? A.block_prefix[(size_t)next_blk * 256 + c] : A.totals[c];
+            cnt = end - first;
+        } else {
+            s_rows[0][c] = s_rows[1][c] = 0;
+        }
+        s_first[c] = first;
+        s_cbase[c + 1] = cnt;  // counts for now
+    }
+    for (int i = t; i < kBinWaves * 256; i += kBinBlock) (&s_wc[0][0])[i] = 0;
     __syncthreads();
-    const uint32_t wave = threadIdx.x >> 6;
-    const size_t i = (size_t)blockIdx.x * kBinBlock + threadIdx.x;
-    const bool in = i < A.n;
-    int ka = 0, kb = 0;
-    uint32_t c = 0xffffffffu;
-    if (in) {
-        ka = A.k[i];
-        kb = A.k[A.n + i];
-        c = bin_class(ka, kb, A.rows, A.g);
+    if (t == 0) {  // counts -> first positions: s_cbase[c + 1] holds the count of class c, s_cbase[0] = 0 (256 serial adds)
+        s_cbase[0] = 0;
+        for (int c = 0; c < 256; c++) s_cbase[c + 1] += s_cbase[c];
     }
-    const bool ok = c != 0xffffffffu;
-    const uint32_t rank = wave_class_rank(c, ok, s_wc[wave]);
     __syncthreads();
-    if (in) A.index[i] = 0xffffffffu;
-    if (!ok) return;
-    uint32_t before = 0;  // pairs of the class in earlier waves of the block
-    for (uint32_t w = 0; w < wave; w++) before += s_wc[w][c];
-    const uint32_t slot = A.block_prefix[(size_t)blockIdx.x * 256 + c] + before + rank;
-    const uint32_t bin = A.class_to_bin[c];
-    A.index[i] = A.pair_base[bin] + slot;
-    const BinDesc D = A.table[bin];
-    const int ra = D.rows_a, rb = D.rows_b;
-    const size_t n = A.n;
-    for (int r = 0; r < ra; r++) {
-        const_cast<float*>(D.ax)[(size_t)r * D.stride + slot] = A.vx[(size_t)r * n + i];
-        const_cast<float*>(D.ay)[(size_t)r * D.stride + slot] = A.vy[(size_t)r * n + i];
+    // ---- slots, index, and the tile's (class, slot) order
+    for (int sub = 0; sub < kMoveSub; sub++) {
+        const uint32_t li = sub * kBinBlock + t;
+        const size_t i = tile0 + li;
+        const bool in = i < A.n;
+        int ka = 0, kb = 0;
+        uint32_t c = 0xffffffffu;
+        if (in) {
+            ka = A.k[i];
+            kb = A.k[A.n + i];
+            c = bin_class(ka, kb, A.rows, A.g);
+        }
+        const bool ok = c != 0xffffffffu;
+        const uint32_t rank = wave_class_rank(c, ok, s_wc[wave]);
+        __syncthreads();
+        s_cls[li] = ok ? (uint16_t)c : (uint16_t)0xffff;
+        if (in) {
+            uint32_t pos = 0xffffffffu;
+            if (ok) {
+                uint32_t before = 0;  // pairs of the class in earlier waves of this 1024-block
+                for (uint32_t w = 0; w < wave; w++) before += s_wc[w][c];
+                const uint32_t slot = A.block_prefix[(size_t)(blk0 + sub) * 256 + c] + before + rank;
+                s_slot[li] = slot;
+                s_sorted[s_cbase[c] + (slot - s_first[c])] = (uint16_t)li;
+                const uint32_t bin = A.class_to_bin[c];
+                pos = A.pair_base[bin] + slot;
+                const BinDesc D = A.table[bin];
+                if (D.ka) {  // (two bytes per pair: written by the pair's own lane)
+                    const_cast<uint8_t*>(D.ka)[slot] = (uint8_t)ka;
+                    const_cast<uint8_t*>(D.kb)[slot] = (uint8_t)kb;
+                }
+            }
+            A.index[i] = pos;
+        }
+        __syncthreads();
+        for (int i2 = t; i2 < kBinWaves * 256; i2 += kBinBlock) (&s_wc[0][0])[i2] = 0;
+        __syncthreads();
     }
-    for (int r = 0; r < rb; r++) {
-        const_cast<float*>(D.bx)[(size_t)r * D.stride + slot] = A.vx[((size_t)A.rows + r) * n + i];
-        const_cast<float*>(D.by)[(size_t)r * D.stride + slot] = A.vy[((size_t)A.rows + r) * n + i];
-    }
-    if (D.ka) {
-        const_cast<uint8_t*>(D.ka)[slot] = (uint8_t)ka;
-        const_cast<uint8_t*>(D.kb)[slot] = (uint8_t)kb;
+    const uint32_t n_valid = s_cbase[256];
+    const uint32_t here = (uint32_t)((A.n - tile0) < (size_t)kMoveTile ? (A.n - tile0) : (size_t)kMoveTile);
+    // ---- every vertex row of every plane through the stage
+    for (int poly = 0; poly < 2; poly++) {
+        for (int r = 0; r < A.rows; r++) {
+            const size_t row = ((size_t)poly * A.rows + r) * A.n + tile0;
+            for (uint32_t e = t; e < here; e += kBinBlock) {
+                s_stage[0][e] = A.vx[row + e];
+                s_stage[1][e] = A.vy[row + e];
+            }
+            __syncthreads();
+            for (uint32_t sp = t; sp < n_valid; sp += kBinBlock) {
+                const uint32_t li = s_sorted[sp];
+                const uint32_t c = s_cls[li];
+                if (r < (int)s_rows[poly][c]) {
+                    const size_t at = (size_t)r * s_stride[c] + s_slot[li];
+                    s_plane[poly * 2][c][at] = s_stage[0][li];
+                    s_plane[poly * 2 + 1][c][at] = s_stage[1][li];
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -756,8 +832,10 @@ int c2d_poly_bins_from_padded(c2d_ctx* ctx, const float* d_vx, const float* d_vy
     A.class_to_bin = reinterpret_cast<const uint16_t*>(base + off_c2b);
     A.pair_base = reinterpret_cast<const uint32_t*>(base + off_base);
     A.block_prefix = d_hist;
+    A.totals = d_totals;
+    A.n_blocks = (uint32_t)n_blocks;
     A.index = B->d_index;
-    hipLaunchKernelGGL(poly_bin_move_kernel, dim3((unsigned)n_blocks), dim3(kBinBlock), 0, s, A);  // (n < 2^32: n_blocks < 2^22)
+    hipLaunchKernelGGL(poly_bin_move_kernel, dim3((unsigned)((n + kMoveTile - 1) / kMoveTile)), dim3(kBinBlock), 0, s, A);  // (n < 2^32)
     C2D_BIN_HIP(hipStreamSynchronize(s));  // (the host vectors above must outlive their copies)
 #undef C2D_BIN_HIP
     if (B->had_bad_counts) {
