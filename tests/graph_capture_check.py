@@ -68,6 +68,11 @@ def main():
     pose_out = torch.zeros(n, dtype=torch.uint8, device=dev)
     mask = torch.zeros((n + 63) // 64, dtype=torch.int64, device=dev)
 
+    # the same polygons as a binned batch (made before the capture: building the table synchronises); test + results are capturable
+    bins = eng.poly_bins_from_padded(pvx.data_ptr(), pvy.data_ptr(), pk.data_ptr(), npoly, 16, 2)
+    bout = torch.zeros(npoly, dtype=torch.uint8, device=dev)
+    bcnt = torch.zeros(1, dtype=torch.int64, device=dev)
+
     g = torch.cuda.CUDAGraph()
     side = torch.cuda.Stream(device=dev)
     with torch.cuda.graph(g, stream=side):
@@ -80,6 +85,8 @@ def main():
         eng.sat_poly_pairs(pvx.data_ptr(), pvy.data_ptr(), pk.data_ptr(), npoly, pout.data_ptr(), pcnt.data_ptr(), stream=sh)
         eng.sat_rect_pairs_pose([row(pose, k) for k in range(10)], n, pose_out.data_ptr(), None, stream=sh)
         eng.sat_rect_pairs_verts_mask([row(planes, k) for k in range(16)], n, mask.data_ptr(), None, stream=sh)
+        eng.sat_poly_pairs_binned(bins, bcnt.data_ptr(), stream=sh)
+        bins.results(bout.data_ptr(), stream=sh)
     torch.cuda.synchronize()
     assert int(cnt.item()) == 0 and not out.any(), "capture must not execute anything"
     for _ in range(3):
@@ -95,6 +102,7 @@ def main():
     assert np.array_equal(d_h.get(), ref_h) and np.array_equal(d_u.get(), ref_u)   # scenes re-zero their counters per call
     ref_poly, ref_pcnt = oracle.sat_poly_pairs(pvx_h, pvy_h, pk_h)
     assert np.array_equal(pout.cpu().numpy(), ref_poly) and int(pcnt.item()) == 3 * ref_pcnt
+    assert np.array_equal(bout.cpu().numpy(), ref_poly) and int(bcnt.item()) == 3 * ref_pcnt
     assert np.array_equal(pose_out.cpu().numpy(), ref_out)
     assert np.array_equal(np.unpackbits(mask.cpu().numpy().view(np.uint8), bitorder="little")[:n], ref_out)
     eng.check_async()
