@@ -581,6 +581,7 @@ def main() -> None:
         # ---- the same 1e7 pairs as a BINNED batch (include/c2d.h "binned polygon batches"): one bin per (ka, kb), so the bytes
         # that move are the vertices (+ one result byte).  The binning pass is a one-off conversion, timed separately.
         torch.cuda.synchronize()
+        eng.poly_bins_from_padded(vx.data_ptr(), vy.data_ptr(), kk.data_ptr(), npoly, KMAX, args.poly_bin_granularity, stream=sh).close()  # allocator warm
         tb0 = time.perf_counter()
         bins = eng.poly_bins_from_padded(vx.data_ptr(), vy.data_ptr(), kk.data_ptr(), npoly, KMAX, args.poly_bin_granularity, stream=sh)
         bin_ms = (time.perf_counter() - tb0) * 1e3
@@ -624,8 +625,9 @@ def main() -> None:
                                                          "the bins themselves move %.1f B/pair" % (moved / npoly),
                                            "traffic": None, "step_ms_distribution": step_distribution(binned_step, preps)},
                               "binning_pass_ms": round(bin_ms, 3),
-                              "binning_note": "c2d_poly_bins_from_padded: one-off conversion of the padded batch (a stable counting sort that moves every vertex "
-                                              "once), not part of a test; results are returned in the padded order by c2d_poly_bins_results",
+                              "binning_note": "c2d_poly_bins_from_padded, second call (wall time incl. the allocation of the bins' block): one-off conversion of "
+                                              "the padded batch (a stable counting sort that moves every vertex once), not part of a test; results are "
+                                              "returned in the padded order by c2d_poly_bins_results",
                               "parity": f"booleans equal to the padded entry point's on {same} of {npoly} pairs"}
         c = counts.get("sat_poly_binned.config5")
         if c and npoly == c.get("pairs") and args.poly_bin_granularity == 1:
