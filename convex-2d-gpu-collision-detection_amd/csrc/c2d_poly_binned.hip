@@ -23,7 +23,7 @@
 
 namespace c2d {
 
-constexpr int kBinSlots = 12;            // undecided pairs parked in LDS at once: the largest multiple of the pairs per trip below it is used
+constexpr int kBinSlots = 12;            // LDS slots for parked (undecided) pairs; a round parks whole trips only (see `slots`)
 constexpr int kSlotF2 = 2 * C2D_POLY_KMAX + 2;  // float2 per slot: 32 vertices + 16 bytes, so that the slots start on different banks
 
 // launch-table entry (device memory, read through the scalar cache).  Polygon "A" of the table is the one with MORE

@@ -190,8 +190,10 @@ int c2d_sat_poly_pairs(c2d_ctx* ctx, const float* d_vx, const float* d_vy, const
  * C2D_POLY_KMAX — d_vx, d_vy : f32[2][rows][n], vertex counts 1..rows, 1 <= rows <= C2D_POLY_KMAX.
  * Batches of small polygons (triangles and quadrilaterals: rows = 4; up to octagons: rows = 8) take
  * a quarter or half of the memory and run a kernel instance sized for them (fewer registers, more
- * waves per SIMD, four or eight pairs per wave in the full evaluation).  rows = C2D_POLY_KMAX is
- * c2d_sat_poly_pairs. */
+ * waves per SIMD, four or eight pairs per wave in the full evaluation); layouts of 9 .. 15 rows run as
+ * one bin of the binned kernel below (its 12- and 16-row instances).  rows = C2D_POLY_KMAX is
+ * c2d_sat_poly_pairs.  A batch whose pairs are ordered by vertex counts moves only the rows its waves
+ * need (16-row instance: a wave skips every row above its largest count). */
 int c2d_sat_poly_pairs_rows(c2d_ctx* ctx, const float* d_vx, const float* d_vy, const uint8_t* d_k,
                             size_t n, int rows, uint8_t* d_out, unsigned long long* d_count,
                             c2d_stream stream);
@@ -205,7 +207,8 @@ int c2d_sat_poly_pairs_rows(c2d_ctx* ctx, const float* d_vx, const float* d_vy, 
  * bytes instead, and the bin's row counts are known before any count byte has been read:
  *
  *   bin:  rows_a, rows_b        vertex rows of polygon A / B in this bin, 1..C2D_POLY_KMAX
- *         n                     pairs in the bin (any number, < 2^32)
+ *         n                     pairs in the bin (any number, < 2^32; every vertex plane — rows x stride
+ *                               floats — must stay below 4 GiB: split larger bins)
  *         stride                elements between the vertex rows of a plane (0 = n; a multiple of 64
  *                               with 256-byte aligned planes keeps every row segment aligned)
  *         d_ax, d_ay            f32[rows_a][stride]  polygon A's vertices, pair index fastest
