@@ -338,3 +338,36 @@ def test_non_finite_polygons_numpy_and_c_agree(oracle, wl):
     touched = np.flatnonzero(~(np.isfinite(bx).all(axis=(0, 1)) & np.isfinite(by).all(axis=(0, 1))))
     for i in touched[:25]:
         assert sat.poly_collide(bx[0, :, i], by[0, :, i], int(k[0, i]), bx[1, :, i], by[1, :, i], int(k[1, i])) == got_c[i]
+
+
+def test_sat_agrees_with_exact_rational_arithmetic_away_from_the_boundary(oracle, wl):
+    """An anchor outside this repository's own arithmetic: the separating-axis predicate of utils.cu:159-184 evaluated in exact
+    rational arithmetic (fractions) on the same float32 vertices.  Wherever every axis' exact gap or overlap exceeds the float32
+    rounding of its projections, the float32 oracle must give the same boolean — on random pairs that is all but a handful."""
+    from fractions import Fraction
+
+    poses = wl.random_obb_pose_planes(3000, seed=123, extent=3.0)
+    r1 = oracle.rects_from_poses(*poses[:5])
+    r2 = oracle.rects_from_poses(*poses[5:])
+    got, _ = oracle.sat_rect_pairs_verts(np.concatenate([r1, r2]))
+    decided = 0
+    for i in range(r1.shape[1]):
+        a = [Fraction(float(v)) for v in r1[:, i]]
+        b = [Fraction(float(v)) for v in r2[:, i]]
+        exact_collide, safe = True, True
+        for r in (a, b):
+            for e in range(4):
+                nx = r[(e + 1) * 2 % 8] - r[e * 2]
+                ny = r[((e + 1) * 2 + 1) % 8] - r[e * 2 + 1]
+                p1 = [nx * a[2 * k] + ny * a[2 * k + 1] for k in range(4)]
+                p2 = [nx * b[2 * k] + ny * b[2 * k + 1] for k in range(4)]
+                gap = max(min(p2) - max(p1), min(p1) - max(p2))          # > 0: separated on this axis
+                scale = max(abs(v) for v in p1 + p2) + Fraction(1, 10**30)
+                if abs(gap) < scale * Fraction(1, 2**18):                  # within ~64 ulp of the decision: rounding may decide
+                    safe = False
+                if gap > 0:
+                    exact_collide = False
+        if safe:
+            decided += 1
+            assert int(exact_collide) == got[i], i
+    assert decided > 2900
