@@ -38,7 +38,7 @@ clean:
 	rm -f $(OBJS) $(LIBDIR)/libc2d.so $(BINDIR)/generate_dataset $(BINDIR)/compute_collision_probability $(BINDIR)/ztest
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle drivers tools clean lib-fmad lib-nopretest lib-rehearsal
+.PHONY: all lib oracle drivers tools clean lib-fmad lib-nopretest lib-rehearsal lib-mcstats
 
 # developer tools (not shipped in libc2d.so)
 TOOLS := $(CSRC)/tools/sat_tune $(CSRC)/tools/pose_probe $(CSRC)/tools/clock_probe $(CSRC)/tools/instr_probe
@@ -71,3 +71,11 @@ $(CSRC)/c2d_dist_rehearsal.o: $(CSRC)/c2d_dist.hip $(HDRS)
 $(REHDIR)/libc2d.so: $(OBJS) $(CSRC)/c2d_dist_rehearsal.o
 	@mkdir -p $(REHDIR)
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(filter-out $(CSRC)/c2d_dist.o,$(OBJS)) $(CSRC)/c2d_dist_rehearsal.o -ldl
+
+# census build (developer tool, not part of `all`): Monte-Carlo kernels that count where their samples go (C2D_MC_STATS in c2d_mc.hip);
+# tests/tools/mc_stats.py reads the counters and records the evaluated-sample fraction the bench quotes
+lib-mcstats: $(LIBDIR)/libc2d_mcstats.so
+$(CSRC)/c2d_mc_stats.o: $(CSRC)/c2d_mc.hip $(HDRS)
+	$(HIPCC) $(HIPFLAGS) -DC2D_MC_STATS -c $< -o $@
+$(LIBDIR)/libc2d_mcstats.so: $(OBJS) $(CSRC)/c2d_mc_stats.o
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(filter-out $(CSRC)/c2d_mc.o,$(OBJS)) $(CSRC)/c2d_mc_stats.o -ldl

@@ -26,6 +26,23 @@
 
 namespace c2d {
 
+// ---- census build (-DC2D_MC_STATS, `make lib-mcstats`; never the product): where the samples of a workload go.  Wave-uniform
+// counts are added to eight device words — [0] samples handed to a wave, [1] of those on the FAR path, [2] on the NEAR path,
+// [3] candidates left by the radius-word test (far path), [4] first Box-Muller pairs evaluated (centre of the obstacle),
+// [5] samples that reach the full evaluation, [6] full-evaluation passes (64 lanes each) in which a second axis of a
+// parallel pair had to be evaluated after all, [7] hits, [8] evaluated samples that the robot's axes do not separate, [9] of
+// those the ones queued for a later pass over the obstacle's axes — and read by c2d_debug_mc_stats (tests/tools/mc_stats.py).
+#ifdef C2D_MC_STATS
+__device__ unsigned long long c2d_mc_stats_words[12];
+#define C2D_MC_STAT(i, v)                                                                                     \
+    do {                                                                                                      \
+        const unsigned long long v__ = (unsigned long long)(v);                                               \
+        if ((threadIdx.x & 63) == 0 && v__) atomicAdd(&c2d_mc_stats_words[i], v__);                           \
+    } while (0)
+#else
+#define C2D_MC_STAT(i, v) do { } while (0)
+#endif
+
 // One wave per block: a multi-wave block keeps its LDS and its place until the slowest of its waves is done, and the
 // work items differ by 4x in cost (config-4 shard 765 -> 751 ms, reference-default batch 58.8 -> 57.2 ms against 256 threads).
 constexpr int kMcBlock = 64;
@@ -217,11 +234,12 @@ C2D_DEV void sample_centre(const Scene& sc, uint32_t radius_word, uint32_t angle
 }
 
 C2D_DEV void sample_obstacle(const Scene& sc, uint32_t radius_word, uint32_t angle_word, float dx, float dy, uint64_t seed,
-                             uint64_t scene_id, uint64_t sample, float (&o)[8])
+                             uint64_t scene_id, uint64_t sample, float (&o)[8], float& dt)
 {
     float n2, n3;
     box_muller(radius_word, angle_word, n2, n3);
-    const float dt = n2 * sc.st, dw = n3 * sc.sw;
+    dt = n2 * sc.st;
+    const float dw = n3 * sc.sw;
     float dh = 0.0f;
     if (sc.sh != 0.0f) {  // wave-uniform
         const U4 b = philox_draw_block(seed, scene_id, sample >> 2, 4u + ((uint32_t)(sample >> 1) & 1u));
@@ -265,6 +283,69 @@ C2D_DEV unsigned long long axis_separates_mask(float ax, float ay, const float (
     return __builtin_amdgcn_ballot_w64(max1 < min2) | __builtin_amdgcn_ballot_w64(max2 < min1);
 }
 
+#ifndef C2D_MC_NO_AXIS_SKIP
+// The two halves of the test below (see its comment for the certificates).  `among`: the lanes whose answer is wanted;
+// returns those of them that no axis of the half separates.
+C2D_DEV unsigned long long robot_axes_survivors(const Scene& sc, const float (&o)[8], unsigned long long among)
+{
+    unsigned long long sep = 0;
+    unsigned long long thin[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {  // robot axes 0, 1 (the robot's own interval is wave-uniform)
+        const float ax = sc.robot[2 * i + 2] - sc.robot[2 * i], ay = sc.robot[2 * i + 3] - sc.robot[2 * i + 1];
+        const float r0 = dot2(ax, sc.robot[0], ay, sc.robot[1]), r1 = dot2(ax, sc.robot[2], ay, sc.robot[3]);
+        const float r2 = dot2(ax, sc.robot[4], ay, sc.robot[5]), r3 = dot2(ax, sc.robot[6], ay, sc.robot[7]);
+        const float q0 = dot2(ax, o[0], ay, o[1]), q1 = dot2(ax, o[2], ay, o[3]);
+        const float q2 = dot2(ax, o[4], ay, o[5]), q3 = dot2(ax, o[6], ay, o[7]);
+        const float rmin = min4(r0, r1, r2, r3), rmax = max4(r0, r1, r2, r3);
+        const float omin = min4(q0, q1, q2, q3), omax = max4(q0, q1, q2, q3);
+        sep |= __builtin_amdgcn_ballot_w64(rmax < omin) | __builtin_amdgcn_ballot_w64(omax < rmin);
+        thin[i] = __builtin_amdgcn_ballot_w64(omax < sc.skip_lo[i]) | __builtin_amdgcn_ballot_w64(omin > sc.skip_hi[i]);
+    }
+    if ((among & ~sep) == 0ull) return 0ull;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        if ((thin[i] & among & ~sep) != 0ull) {  // axis i + 2 in full
+            C2D_MC_STAT(6, 1);
+            const float ax = sc.robot[(2 * i + 6) & 7] - sc.robot[2 * i + 4], ay = sc.robot[(2 * i + 7) & 7] - sc.robot[2 * i + 5];
+            sep |= axis_separates_mask(ax, ay, sc.robot, o);
+        }
+    }
+    return among & ~sep;
+}
+
+C2D_DEV unsigned long long obstacle_axes_survivors(const Scene& sc, const float (&o)[8], unsigned long long among)
+{
+    unsigned long long sep = 0;
+    unsigned long long thin2[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {  // obstacle axes 4, 5, with the per-sample certificate for 6, 7
+        const float ax = o[2 * j + 2] - o[2 * j], ay = o[2 * j + 3] - o[2 * j + 1];
+        const float bx = o[(2 * j + 6) & 7] - o[2 * j + 4], by = o[(2 * j + 7) & 7] - o[2 * j + 5];  // obstacle edge j + 2
+        const float r0 = dot2(ax, sc.robot[0], ay, sc.robot[1]), r1 = dot2(ax, sc.robot[2], ay, sc.robot[3]);
+        const float r2 = dot2(ax, sc.robot[4], ay, sc.robot[5]), r3 = dot2(ax, sc.robot[6], ay, sc.robot[7]);
+        const float q0 = dot2(ax, o[0], ay, o[1]), q1 = dot2(ax, o[2], ay, o[3]);
+        const float q2 = dot2(ax, o[4], ay, o[5]), q3 = dot2(ax, o[6], ay, o[7]);
+        const float min1 = min4(r0, r1, r2, r3), max1 = max4(r0, r1, r2, r3);
+        const float min2 = min4(q0, q1, q2, q3), max2 = max4(q0, q1, q2, q3);
+        sep |= __builtin_amdgcn_ballot_w64(max1 < min2) | __builtin_amdgcn_ballot_w64(max2 < min1);
+        const float need = fma_(__builtin_fabsf(ax) + __builtin_fabsf(ay), sc.skip_c3,
+                                (__builtin_fabsf(ax + bx) + __builtin_fabsf(ay + by)) * sc.skip_c2) + 1e-36f;
+        thin2[j] = __builtin_amdgcn_ballot_w64(max2 - min1 < need) | __builtin_amdgcn_ballot_w64(max1 - min2 < need);
+    }
+    if ((among & ~sep) == 0ull) return 0ull;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        if ((thin2[j] & among & ~sep) != 0ull) {  // axis j + 6 in full
+            C2D_MC_STAT(6, 1);
+            const float bx = o[(2 * j + 6) & 7] - o[2 * j + 4], by = o[(2 * j + 7) & 7] - o[2 * j + 5];
+            sep |= axis_separates_mask(bx, by, sc.robot, o);
+        }
+    }
+    return among & ~sep;
+}
+#endif
+
 // lanes whose sample collides (no axis separates it): convex_collide(robot, obstacle), utils.cu:159-184.
 //
 // All eight axes are part of the reference's result.  Two kinds of work are left out here, neither of which can change a
@@ -285,8 +366,8 @@ C2D_DEV unsigned long long axis_separates_mask(float ax, float ay, const float (
 C2D_DEV unsigned long long sample_collides_mask(const Scene& sc, const float (&o)[8])
 {
     const unsigned long long lanes = wave_lanes();
-    unsigned long long sep = 0;
 #ifdef C2D_MC_NO_AXIS_SKIP
+    unsigned long long sep = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         float ax, ay;
@@ -303,54 +384,9 @@ C2D_DEV unsigned long long sample_collides_mask(const Scene& sc, const float (&o
     }
     return lanes & ~sep;
 #else
-    // ---- robot axes 0, 1 (the robot's own interval is wave-uniform)
-    unsigned long long thin[2];
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const float ax = sc.robot[2 * i + 2] - sc.robot[2 * i], ay = sc.robot[2 * i + 3] - sc.robot[2 * i + 1];
-        const float r0 = dot2(ax, sc.robot[0], ay, sc.robot[1]), r1 = dot2(ax, sc.robot[2], ay, sc.robot[3]);
-        const float r2 = dot2(ax, sc.robot[4], ay, sc.robot[5]), r3 = dot2(ax, sc.robot[6], ay, sc.robot[7]);
-        const float q0 = dot2(ax, o[0], ay, o[1]), q1 = dot2(ax, o[2], ay, o[3]);
-        const float q2 = dot2(ax, o[4], ay, o[5]), q3 = dot2(ax, o[6], ay, o[7]);
-        const float rmin = min4(r0, r1, r2, r3), rmax = max4(r0, r1, r2, r3);
-        const float omin = min4(q0, q1, q2, q3), omax = max4(q0, q1, q2, q3);
-        sep |= __builtin_amdgcn_ballot_w64(rmax < omin) | __builtin_amdgcn_ballot_w64(omax < rmin);
-        thin[i] = __builtin_amdgcn_ballot_w64(omax < sc.skip_lo[i]) | __builtin_amdgcn_ballot_w64(omin > sc.skip_hi[i]);
-    }
-    if ((lanes & ~sep) == 0ull) return 0ull;
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        if ((thin[i] & lanes & ~sep) != 0ull) {  // axis i + 2 in full
-            const float ax = sc.robot[(2 * i + 6) & 7] - sc.robot[2 * i + 4], ay = sc.robot[(2 * i + 7) & 7] - sc.robot[2 * i + 5];
-            sep |= axis_separates_mask(ax, ay, sc.robot, o);
-        }
-    }
-    // ---- obstacle axes 4, 5, with the per-sample certificate for 6, 7
-    unsigned long long thin2[2];
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const float ax = o[2 * j + 2] - o[2 * j], ay = o[2 * j + 3] - o[2 * j + 1];
-        const float bx = o[(2 * j + 6) & 7] - o[2 * j + 4], by = o[(2 * j + 7) & 7] - o[2 * j + 5];  // obstacle edge j + 2
-        const float r0 = dot2(ax, sc.robot[0], ay, sc.robot[1]), r1 = dot2(ax, sc.robot[2], ay, sc.robot[3]);
-        const float r2 = dot2(ax, sc.robot[4], ay, sc.robot[5]), r3 = dot2(ax, sc.robot[6], ay, sc.robot[7]);
-        const float q0 = dot2(ax, o[0], ay, o[1]), q1 = dot2(ax, o[2], ay, o[3]);
-        const float q2 = dot2(ax, o[4], ay, o[5]), q3 = dot2(ax, o[6], ay, o[7]);
-        const float min1 = min4(r0, r1, r2, r3), max1 = max4(r0, r1, r2, r3);
-        const float min2 = min4(q0, q1, q2, q3), max2 = max4(q0, q1, q2, q3);
-        sep |= __builtin_amdgcn_ballot_w64(max1 < min2) | __builtin_amdgcn_ballot_w64(max2 < min1);
-        const float need = fma_(__builtin_fabsf(ax) + __builtin_fabsf(ay), sc.skip_c3,
-                                (__builtin_fabsf(ax + bx) + __builtin_fabsf(ay + by)) * sc.skip_c2) + 1e-36f;
-        thin2[j] = __builtin_amdgcn_ballot_w64(max2 - min1 < need) | __builtin_amdgcn_ballot_w64(max1 - min2 < need);
-    }
-    if ((lanes & ~sep) == 0ull) return 0ull;
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        if ((thin2[j] & lanes & ~sep) != 0ull) {  // axis j + 6 in full
-            const float bx = o[(2 * j + 6) & 7] - o[2 * j + 4], by = o[(2 * j + 7) & 7] - o[2 * j + 5];
-            sep |= axis_separates_mask(bx, by, sc.robot, o);
-        }
-    }
-    return lanes & ~sep;
+    const unsigned long long alive = robot_axes_survivors(sc, o, lanes);
+    if (alive == 0ull) return 0ull;
+    return obstacle_axes_survivors(sc, o, alive);
 #endif
 }
 
@@ -379,6 +415,9 @@ struct WaveQueue {
     // The scene fields that only the full evaluation reads (park_scene / load_eval): 24 floats, read back as six
     // broadcast ds_read_b128 per 64 evaluated samples instead of living in two dozen VGPRs through every sample loop
     float4 ev[6];
+    // Survivors of the robot's axes waiting for the obstacle's axes (evaluate_samples): centre and rotation angle, from which
+    // the obstacle is rebuilt.  < 64 left over + at most 63 pushed by a pass.
+    float sv_dx[128], sv_dy[128], sv_dt[128];
     union {
         struct {
             float4 cw[kQueueSlots];      // dx, dy, bits(radius word 2), bits(angle word 2)
@@ -452,6 +491,79 @@ C2D_DEV Scene load_eval(const Scene& hot, const WaveQueue& q)
     return sc;
 }
 
+// ---- the full evaluation of up to 64 samples, in two stages with a compaction in between ------------------------------
+// On the dataset workloads most samples that reach the full evaluation are misses after all (config-4 shard: 5.7 % of the
+// drawn samples are evaluated, 0.74 % hit; reference-default batch: 12 % and 0.8 %; tests/tools/mc_stats.py), and the
+// robot's axes — whose robot-side interval is a scene constant — separate nearly all of those.  So a pass evaluates the
+// robot's axes for its 64 samples, and only the SURVIVORS go on to the obstacle's axes (the dearer half: both rectangles are
+// projected per sample): their centre and rotation angle are pushed to a third per-wave queue, and when 64 have gathered the
+// obstacle is rebuilt for them (same floats: sincos of the same angle, the same products) and its axes evaluated on 64 busy
+// lanes.  When most lanes of a pass survive (a scene with p ~ 0.5: config 3) the obstacle's axes are evaluated in place
+// instead, as before.  Shapes with width / height noise keep their extents per sample and are always evaluated in place.
+// The result is the same OR over the same eight axes in another order.  Measured: see DESIGN.md §5.
+#ifndef C2D_MC_IN_PLACE_FROM
+#define C2D_MC_IN_PLACE_FROM 40  // survivors among a pass's 64 samples from which the obstacle's axes run in place
+#endif
+
+// the obstacle's axes for `take` queued survivors (take <= 64, the last ones pushed)
+C2D_DEV uint32_t drain_survivors(const Scene& ev, WaveQueue& wq, uint32_t& sn, uint32_t take)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t src = sn - take + (lane < take ? lane : 0);
+    const float dx = wq.sv_dx[src], dy = wq.sv_dy[src], dt = wq.sv_dt[src];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    sn -= take;
+    float s, c, o[8];
+    sincos_(dt, s, c);
+    rect_from_half_extents(ev.hw, ev.hh, c, s, dx, dy, o);  // (fixed shape: dw = dh = +-0, the half extents are the scene's)
+    const unsigned long long live_m = take >= 64 ? ~0ull : (1ull << take) - 1;
+#ifdef C2D_MC_NO_AXIS_SKIP
+    (void)live_m;
+    return 0;  // (never called in the validation build)
+#else
+    return (uint32_t)__popcll(obstacle_axes_survivors(ev, o, live_m));
+#endif
+}
+
+// hits among the (up to 64, mask live_m) samples of a pass that are decided by this call; survivors may stay queued
+template <bool PARKED>
+C2D_DEV uint32_t evaluate_samples(const Scene& sc, WaveQueue& wq, uint32_t& sn, uint32_t w2r, uint32_t w2a, float dx, float dy, uint64_t seed,
+                                  uint64_t scene_id, uint64_t sample, unsigned long long live_m)
+{
+    const Scene ev = load_eval<PARKED>(sc, wq);
+    C2D_MC_STAT(5, __popcll(live_m));
+    float o[8], dt;
+    sample_obstacle(ev, w2r, w2a, dx, dy, seed, scene_id, sample, o, dt);
+#ifdef C2D_MC_NO_AXIS_SKIP
+    return (uint32_t)__popcll(sample_collides_mask(ev, o) & live_m);
+#else
+    const unsigned long long surv = robot_axes_survivors(ev, o, live_m);
+    if (surv == 0ull) return 0;
+    // mc_pair_kernel (PARKED == false: one scene, every wave on the same scene) always goes on in place: on the config-3 scene
+    // 85 % of the evaluated samples survive the robot's axes, and the queue's bookkeeping alone costs it 2 % (0.545 -> 0.557 ms)
+    if constexpr (!PARKED) return (uint32_t)__popcll(obstacle_axes_survivors(ev, o, surv));
+    const uint32_t ns = (uint32_t)__popcll(surv);
+    C2D_MC_STAT(8, ns);
+    if (ns >= (uint32_t)C2D_MC_IN_PLACE_FROM || ev.sw != 0.0f || ev.sh != 0.0f) return (uint32_t)__popcll(obstacle_axes_survivors(ev, o, surv));
+    const uint32_t lane = threadIdx.x & 63;
+    if ((surv >> lane) & 1ull) {
+        const uint32_t slot = sn + __builtin_amdgcn_mbcnt_hi((uint32_t)(surv >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)surv, 0u));
+        wq.sv_dx[slot] = dx;
+        wq.sv_dy[slot] = dy;
+        wq.sv_dt[slot] = dt;
+    }
+    sn += ns;
+    C2D_MC_STAT(9, ns);
+    if (sn < 64) return 0;
+    return drain_survivors(ev, wq, sn, 64);
+#endif
+}
+
 #ifndef C2D_MC_PARK_ADAPTIVE
 #define C2D_MC_PARK_ADAPTIVE 1  // 0: the adaptive kernels keep the whole scene in registers too (the A/B of profiles/r03_mc_isa.md)
 #endif
@@ -478,6 +590,7 @@ C2D_DEV uint32_t wave_count_hits_near(const Scene& sc, uint64_t seed, uint64_t s
     auto& q = wq.near;
     const uint32_t lane = threadIdx.x & 63;
     uint32_t hits = 0;    // wave-uniform (scalar) accumulator
+    uint32_t sn = 0;      // survivors of the robot's axes waiting for the obstacle's (evaluate_samples)
     uint32_t qn = 0;      // queued samples (wave-uniform)
     uint32_t dense = 0;   // sub-iterations to evaluate in place after the pretest ruled nothing out
     // (count < 2^31 — the callers cut work into far smaller chunks — keeps every offset below in 32 bits)
@@ -533,6 +646,7 @@ C2D_DEV uint32_t wave_count_hits_near(const Scene& sc, uint64_t seed, uint64_t s
                 unsigned long long m = in_m;          // ... and the same vote as a lane mask
                 if (dense) {  // every lane needs the full evaluation anyway
                     dense--;
+                    C2D_MC_STAT(4, __popcll(in_m));
                     sample_centre(sc, rw, aw, dx, dy);
                     live_m = in_m;
                     direct = true;
@@ -545,6 +659,7 @@ C2D_DEV uint32_t wave_count_hits_near(const Scene& sc, uint64_t seed, uint64_t s
                     }
                     if (m == 0ull) continue;
 #endif
+                    C2D_MC_STAT(4, __popcll(m));
                     sample_centre(sc, rw, aw, dx, dy);
 #ifndef C2D_MC_NO_PRETEST
                     unsigned long long miss_m;
@@ -598,12 +713,12 @@ C2D_DEV uint32_t wave_count_hits_near(const Scene& sc, uint64_t seed, uint64_t s
                 w2r = __float_as_uint(e.z);
                 w2a = __float_as_uint(e.w);
             }
-            float o[8];
-            const Scene ev = load_eval<PARKED>(sc, wq);
-            sample_obstacle(ev, w2r, w2a, dx, dy, seed, scene_id, begin + sidx, o);
-            hits += (uint32_t)__popcll(sample_collides_mask(ev, o) & live_m);
+            hits += evaluate_samples<PARKED>(sc, wq, sn, w2r, w2a, dx, dy, seed, scene_id, begin + sidx, live_m);
             if (flush) break;
         }
+    }
+    if constexpr (PARKED) {
+        if (sn) hits += drain_survivors(load_eval<PARKED>(sc, wq), wq, sn, sn);  // (fewer than 64 are left)
     }
     return hits;
 }
@@ -623,6 +738,7 @@ C2D_DEV uint32_t wave_count_hits_far(const Scene& sc, uint64_t seed, uint64_t sc
     auto& q = wq.far;
     const uint32_t lane = threadIdx.x & 63;
     uint32_t hits = 0, cn = 0, un = 0;  // wave-uniform: hits, queued candidates, queued undecided samples
+    uint32_t sn = 0;                    // survivors of the robot's axes waiting for the obstacle's (evaluate_samples)
     const uint64_t g0 = begin >> 2;
     const uint32_t base = (uint32_t)(begin & 3);
     const uint32_t end_pos = base + count;
@@ -638,6 +754,7 @@ C2D_DEV uint32_t wave_count_hits_far(const Scene& sc, uint64_t seed, uint64_t sc
             q.cand[slot] = make_uint2(word, sidx);
         }
         cn += (uint32_t)__popcll(m);
+        C2D_MC_STAT(3, __popcll(m));
     };
     auto push_block = [&](const U4& r, uint32_t cgi) {
         if (__builtin_amdgcn_ballot_w64((r.x < x0) | (r.y < x0) | (r.z < x0) | (r.w < x0)) == 0ull) return;  // 256 certain misses
@@ -696,6 +813,7 @@ C2D_DEV uint32_t wave_count_hits_far(const Scene& sc, uint64_t seed, uint64_t sc
             const uint32_t jj = (uint32_t)s & 3u;
             const uint32_t aw = jj == 0 ? a.x : (jj == 1 ? a.y : (jj == 2 ? a.z : a.w));
             float dx, dy;
+            C2D_MC_STAT(4, take);
             sample_centre(sc, e.x, aw, dx, dy);
             unsigned long long miss_m;
             const bool miss = centre_pretest(sc, dx, dy, miss_m);  // (every lane votes: no short-circuit around it)
@@ -725,12 +843,12 @@ C2D_DEV uint32_t wave_count_hits_far(const Scene& sc, uint64_t seed, uint64_t sc
             const uint64_t s = begin + sidx;
             const U4 pb = philox_draw_block(seed, scene_id, s >> 2, 2u + ((uint32_t)(s >> 1) & 1u));
             const bool odd = (s & 1) != 0;
-            float o[8];
-            const Scene ev = load_eval<PARKED>(sc, wq);
-            sample_obstacle(ev, odd ? pb.z : pb.x, odd ? pb.w : pb.y, c.x, c.y, seed, scene_id, s, o);
-            hits += (uint32_t)__popcll(sample_collides_mask(ev, o) & live_m);
+            hits += evaluate_samples<PARKED>(sc, wq, sn, odd ? pb.z : pb.x, odd ? pb.w : pb.y, c.x, c.y, seed, scene_id, s, live_m);
         }
         if (drained && cn == 0 && un == 0) break;
+    }
+    if constexpr (PARKED) {
+        if (sn) hits += drain_survivors(load_eval<PARKED>(sc, wq), wq, sn, sn);  // (fewer than 64 are left)
     }
     return hits;
 }
@@ -754,7 +872,8 @@ C2D_DEV uint32_t wave_count_hits_plain(const Scene& sc, uint64_t seed, uint64_t 
         float dx, dy, o[8];
         sample_centre(sc, u4_word(b0, (int)j), u4_word(b1, (int)j), dx, dy);
         const Scene ev = load_eval<PARKED>(sc, wq);
-        sample_obstacle(ev, (j & 1u) ? b2.z : b2.x, (j & 1u) ? b2.w : b2.y, dx, dy, seed, scene_id, s, o);
+        float dt_unused;
+        sample_obstacle(ev, (j & 1u) ? b2.z : b2.x, (j & 1u) ? b2.w : b2.y, dx, dy, seed, scene_id, s, o, dt_unused);
         hits += (uint32_t)__popcll(__ballot(live && rect_collide(ev.robot, o)));
     }
     return hits;
@@ -765,11 +884,20 @@ template <bool PARKED>
 C2D_DEV uint32_t wave_count_hits(const Scene& sc, uint64_t seed, uint64_t scene_id, uint64_t begin, uint32_t count,
                                  WaveQueue& q)
 {
+    C2D_MC_STAT(0, count);
     if (!sc.tame()) return wave_count_hits_plain<PARKED>(sc, seed, scene_id, begin, count, q);
 #ifndef C2D_MC_NO_PRETEST  // validation builds evaluate every sample in full
-    if (sc.use_x0 && sc.x0 < kFarX0) return wave_count_hits_far<PARKED>(sc, seed, scene_id, begin, count, q);
+    if (sc.use_x0 && sc.x0 < kFarX0) {
+        C2D_MC_STAT(1, count);
+        const uint32_t h = wave_count_hits_far<PARKED>(sc, seed, scene_id, begin, count, q);
+        C2D_MC_STAT(7, h);
+        return h;
+    }
 #endif
-    return wave_count_hits_near<PARKED>(sc, seed, scene_id, begin, count, q);
+    C2D_MC_STAT(2, count);
+    const uint32_t h = wave_count_hits_near<PARKED>(sc, seed, scene_id, begin, count, q);
+    C2D_MC_STAT(7, h);
+    return h;
 }
 
 // ---- one scene, sample-parallel (BASELINE config 3) -------------------------------
@@ -1356,6 +1484,22 @@ int c2d_sample_scenes(c2d_ctx* ctx, const Pose* d_poses, uint32_t num_poses, con
     C2D_LAUNCH_CHECK(ctx);
     return C2D_OK;
 }
+
+#ifdef C2D_MC_STATS
+// census build only: copies the twelve counters to the host (after synchronising the device) and optionally clears them
+int c2d_debug_mc_stats(c2d_ctx* ctx, unsigned long long out[12], int reset)
+{
+    if (!ctx || !out) return C2D_ERR_INVALID_ARG;
+    DeviceGuard g(ctx->device);
+    C2D_HIP(ctx, hipDeviceSynchronize());
+    C2D_HIP(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(c2d_mc_stats_words), 12 * sizeof(unsigned long long)));
+    if (reset) {
+        const unsigned long long zero[12] = {};
+        C2D_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c2d_mc_stats_words), zero, sizeof zero));
+    }
+    return C2D_OK;
+}
+#endif
 
 // Host mirrors of the stopping statistics (same expressions as the device code).
 float c2d_calc_slack(uint32_t n, uint32_t k)
