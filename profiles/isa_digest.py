@@ -5,9 +5,9 @@
 
 Compiles the file device-only to assembly with the flags of the top-level Makefile (plus any -D given), then prints,
 per kernel: VGPRs, SGPRs, spill counts, scratch bytes, LDS bytes, occupancy, code size, and static instruction counts
-by class.  With --scratch every scratch_load / scratch_store is listed with the innermost loop it sits in: loops are
-recovered from the assembly's backward branches (a branch at line j to a label at line i <= j makes [i, j] a loop);
-the label of the loop header and its nesting depth are printed, depth 0 = straight-line code outside every loop.
+by class.  With --scratch every scratch_load / scratch_store is listed with the loop depth it executes at, taken from
+LLVM's own block annotations in the assembly ("in Loop: Header=BBx_y Depth=N"): depth 0 = straight-line code outside
+every loop, depth 1 = the kernel's outermost loop (for the adaptive Monte-Carlo kernels: the loop over work items).
 Static counts are not dynamic counts: they say what exists in the code, the PMC passes say what runs.
 """
 from __future__ import annotations
@@ -137,11 +137,18 @@ def digest(src: str, defines: list[str], show_scratch: bool, md_out: bool) -> No
         print(("### " if md_out else "") + head)
         print("    " + ", ".join(f"{c} {counts[c]}" for c in sorted(counts)))
         if show_scratch and counts.get("scratch"):
-            loops = loops_of(body)
+            # LLVM annotates every basic block that sits in a loop ("in Loop: Header=BBx_y Depth=N" / "Loop Header: Depth=N");
+            # the depth of the block a scratch instruction belongs to is the loop depth it executes at
+            depth, header = 0, ""
             for i, ln in enumerate(body):
+                m = re.match(r"^\.LBB\d+_\d+:(.*)$", ln)
+                if m:
+                    d = re.search(r"Depth=(\d+)", m.group(1))
+                    h = re.search(r"Header=(BB\d+_\d+)", m.group(1))
+                    depth = int(d.group(1)) if d else 0
+                    header = h.group(1) if h else (ln.split(":")[0].lstrip(".L") if d else "")
                 if re.match(r"\s+scratch_", ln):
-                    inside = sorted([(e - s, s, e, lab) for (s, e, lab) in loops if s <= i <= e])
-                    where = "outside every loop" if not inside else f"depth {len(inside)}, innermost loop {inside[0][3]} ({inside[0][0]} lines long)"
+                    where = "outside every loop" if depth == 0 else f"loop depth {depth} (header {header})"
                     print(f"      line {i:5d}: {ln.strip():60s} {where}")
         print()
 
