@@ -403,7 +403,8 @@ int c2d_sample_scenes(c2d_ctx* ctx, const Pose* d_poses, uint32_t num_poses,
  * c2d_dist_init and c2d_dist_barrier (hence c2d_dist_init_file) run under a watchdog: if the
  * peers do not arrive within the time limit (timeout_s of c2d_dist_init_file; $C2D_DIST_TIMEOUT_S
  * or 300 s for c2d_dist_init) they return C2D_ERR_DIST instead of blocking for ever; the process
- * should then report the error and end (a helper thread is left inside RCCL).
+ * should then report the error and end (a helper thread is left inside RCCL: after such a
+ * time-out the communicator must neither be used nor destroyed).
  *
  * c2d_dist_transport() names the transport: "rccl" — the only one this library contains.  A
  * separate test build (lib-rehearsal/libc2d.so, `make lib-rehearsal`) replaces it by a sum
