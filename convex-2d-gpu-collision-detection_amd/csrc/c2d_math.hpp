@@ -272,4 +272,46 @@ C2D_DEV bool rect_collide(const float (&r1)[8], const float (&r2)[8])
     return !sep;
 }
 
+// ---- convex_collide with certificates for the second axis of each parallel pair -----------------------------------------
+// A rectangle's edge axes 2, 3 are the negatives of its axes 0, 1 up to rounding: b = -a + d with |d| a few ulps of the
+// coordinates.  For every vertex v the COMPUTED projections satisfy |p_b(v) + p_a(v)| <= eta,
+//     eta = |d|_1 C (1 + 3u) + 4u (1 + u) |a|_1 C,      u = 2^-24, C >= every |coordinate| of the pair
+// (d.v plus the roundings of the two dot products), so max1_b >= -min1_a - eta, min2_b <= -max2_a + eta and likewise with 1, 2
+// exchanged: when both overlaps on axis a, max2_a - min1_a and max1_a - min2_a, are at least 2 eta, NEITHER comparison of
+// utils.cu:178 can hold on axis b.  This evaluates axes 0, 1 of both rectangles, takes d from the floats (a + b) and C from
+// the sixteen coordinates, and reports `thin` when the pair is not separated by those four axes and some overlap is below its
+// certificate (or not a number: the comparisons are written so that a NaN anywhere reads "thin") — the caller then evaluates
+// the pair in full (rect_collide).  The thresholds carry 2^-8 relative and 1e-36 absolute slack for their own rounding and
+// for underflow.  The Monte-Carlo kernels use the same certificates with scene-level constants (c2d_mc.hip).
+C2D_DEV bool rect_collide_certified(const float (&r1)[8], const float (&r2)[8], bool& thin)
+{
+    float cmax = __builtin_fabsf(r1[0]);
+#pragma unroll
+    for (int k = 1; k < 8; k++) cmax = __builtin_fmaxf(cmax, __builtin_fabsf(r1[k]));
+#pragma unroll
+    for (int k = 0; k < 8; k++) cmax = __builtin_fmaxf(cmax, __builtin_fabsf(r2[k]));
+    const float c2 = (2.0f + 0x1p-7f) * cmax, c3 = (8.0f + 0x1p-5f) * 0x1p-24f * cmax;
+    bool sep = false, uneasy = false;
+#pragma unroll
+    for (int which = 0; which < 2; which++) {
+        const float (&r)[8] = which == 0 ? r1 : r2;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const float ax = r[2 * i + 2] - r[2 * i], ay = r[2 * i + 3] - r[2 * i + 1];
+            const float bx = r[(2 * i + 6) & 7] - r[2 * i + 4], by = r[(2 * i + 7) & 7] - r[2 * i + 5];  // edge i + 2
+            const float p10 = dot2(ax, r1[0], ay, r1[1]), p11 = dot2(ax, r1[2], ay, r1[3]);
+            const float p12 = dot2(ax, r1[4], ay, r1[5]), p13 = dot2(ax, r1[6], ay, r1[7]);
+            const float p20 = dot2(ax, r2[0], ay, r2[1]), p21 = dot2(ax, r2[2], ay, r2[3]);
+            const float p22 = dot2(ax, r2[4], ay, r2[5]), p23 = dot2(ax, r2[6], ay, r2[7]);
+            const float min1 = min4(p10, p11, p12, p13), max1 = max4(p10, p11, p12, p13);
+            const float min2 = min4(p20, p21, p22, p23), max2 = max4(p20, p21, p22, p23);
+            sep |= ((max1 < min2) || (max2 < min1)) && first_projections_ordered(p10, p20);
+            const float need = fma_(__builtin_fabsf(ax) + __builtin_fabsf(ay), c3, (__builtin_fabsf(ax + bx) + __builtin_fabsf(ay + by)) * c2) + 1e-36f;
+            uneasy |= !((max2 - min1 >= need) && (max1 - min2 >= need));
+        }
+    }
+    thin = !sep && uneasy;
+    return !sep;
+}
+
 }  // namespace c2d
