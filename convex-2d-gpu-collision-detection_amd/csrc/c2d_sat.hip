@@ -212,15 +212,20 @@ __global__ __launch_bounds__(64) void sat_rect_aos_kernel(const float* __restric
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        uint32_t packed = 0;
+        f32x4 pa[4], pb[4];  // the lane's two pairs: chunks 4 lane .. 4 lane + 3 of each array
 #pragma unroll
-        for (int e = 0; e < 2; e++) {
-            const f32x4 a0 = tile[0][4 * lane + 2 * e], a1 = tile[0][4 * lane + 2 * e + 1];
-            const f32x4 b0 = tile[1][4 * lane + 2 * e], b1 = tile[1][4 * lane + 2 * e + 1];
-            const float r1[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-            const float r2[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-            packed |= (rect_collide(r1, r2) ? 1u : 0u) << (8 * e);
+        for (int c = 0; c < 4; c++) {
+            pa[c] = tile[0][4 * lane + c];
+            pb[c] = tile[1][4 * lane + c];
         }
+        const uint32_t bits = collide_pairs<2>([&pa, &pb](int e, auto how, float (&r1)[8], float (&r2)[8]) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                r1[k] = launder(pa[2 * e + k / 4][k % 4], how);
+                r2[k] = launder(pb[2 * e + k / 4][k % 4], how);
+            }
+        });
+        const uint32_t packed = (bits & 1u) | ((bits & 2u) << 7);
         const size_t i = p0 + 2 * (size_t)lane;
         if (i + 1 < n) {
             if constexpr (OUT16) {
