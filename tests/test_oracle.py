@@ -371,3 +371,32 @@ def test_sat_agrees_with_exact_rational_arithmetic_away_from_the_boundary(oracle
             decided += 1
             assert int(exact_collide) == got[i], i
     assert decided > 2900
+
+
+def test_parallel_axis_certificate_error_bound(oracle, wl):
+    """The bound behind the kernels' certificates (c2d_math.hpp rect_collide_certified, c2d_mc.hip sample_collides_mask): for a
+    rectangle's edge axes a (edge i) and b (edge i + 2), d = a + b, every float32 projection satisfies
+    |p_b(v) + p_a(v)| <= |d|_1 C (1 + 3u) + 4u (1 + u) |a|_1 C with C >= every |coordinate|.  Checked in float64 on 300 000
+    rectangle pairs at several scales; the largest observed ratio is close to one (the d-term is attained), which is why the
+    kernels' thresholds are the bound itself plus 2^-8, not a fraction of it."""
+    F, u, worst = np.float32, 2.0 ** -24, 0.0
+    for seed, extent, scale in ((1, 8.0, 1.0), (2, 1.0, 1.0), (3, 100.0, 1.0), (4, 8.0, 1e-3), (5, 8.0, 1e4), (6, 0.01, 1.0)):
+        poses = wl.random_obb_pose_planes(50_000, seed=seed, extent=extent)
+        r1 = (oracle.rects_from_poses(*poses[:5]) * F(scale)).astype(F)
+        r2 = (oracle.rects_from_poses(*poses[5:]) * F(scale)).astype(F)
+        C = np.maximum(np.abs(r1).max(0), np.abs(r2).max(0)).astype(np.float64)
+        for r in (r1, r2):
+            for i in range(2):
+                ax, ay = (r[2 * i + 2] - r[2 * i]).astype(F), (r[2 * i + 3] - r[2 * i + 1]).astype(F)
+                bx, by = (r[(2 * i + 6) & 7] - r[2 * i + 4]).astype(F), (r[(2 * i + 7) & 7] - r[2 * i + 5]).astype(F)
+                d1 = np.abs(ax.astype(np.float64) + bx) + np.abs(ay.astype(np.float64) + by)
+                a1 = np.abs(ax.astype(np.float64)) + np.abs(ay.astype(np.float64))
+                bound = d1 * C * (1 + 3 * u) + 4 * u * (1 + u) * a1 * C
+                for rr in (r1, r2):
+                    for k in range(4):
+                        pa = ((ax * rr[2 * k]).astype(F) + (ay * rr[2 * k + 1]).astype(F)).astype(F)
+                        pb = ((bx * rr[2 * k]).astype(F) + (by * rr[2 * k + 1]).astype(F)).astype(F)
+                        e = np.abs(pa.astype(np.float64) + pb.astype(np.float64))
+                        assert (e <= bound).all(), (seed, i, k)
+                        worst = max(worst, float(np.where(bound > 0, e / np.where(bound > 0, bound, 1), 0).max()))
+    assert 0.5 < worst <= 1.0
