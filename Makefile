@@ -49,7 +49,7 @@ $(CSRC)/tools/%: $(CSRC)/tools/%.hip $(HDRS)
 # validation build: Monte-Carlo kernels without the certain-miss pretests (tests/test_gpu_fullsize.py, tools/validate_*.py)
 lib-nopretest: $(LIBDIR)/libc2d_nopretest.so
 $(CSRC)/c2d_mc_nopretest.o: $(CSRC)/c2d_mc.hip $(HDRS)
-	$(HIPCC) $(HIPFLAGS) -DC2D_MC_NO_PRETEST -DC2D_MC_NO_AXIS_SKIP -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) -DC2D_MC_NO_PRETEST -DC2D_MC_NO_AXIS_SKIP -DC2D_MC_NO_MODEL_TEST -c $< -o $@
 $(LIBDIR)/libc2d_nopretest.so: $(OBJS) $(CSRC)/c2d_mc_nopretest.o
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(filter-out $(CSRC)/c2d_mc.o,$(OBJS)) $(CSRC)/c2d_mc_nopretest.o -ldl
 

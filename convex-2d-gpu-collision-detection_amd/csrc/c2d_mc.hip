@@ -62,6 +62,9 @@ struct Scene {
     // negatives of axes 0, 1 up to rounding, so when the two intervals overlap by enough on axis i, axis i + 2 cannot separate
     float skip_lo[2], skip_hi[2];  // robot axes: obstacle interval must reach [.., skip_lo] and [skip_hi, ..] on axis 0 / 1
     float skip_c2, skip_c3;        // obstacle axes: needed overlap = c2 |a + b|_1 + c3 |a|_1 (a, b: the two axes of the pair)
+    // Closed-form test of a full evaluation (model_gap): the robot as centre, rotation and half extents, and the margin
+    // within which the closed form does not decide (+inf: never decides, every evaluation takes the vertex arithmetic)
+    float mrx, mry, mcr, msr, mhw, mhh, margin;
     // use_x0 == false && x0 == 0 marks a scene that is not "tame": some parameter is NaN, infinite or >= 1e15 in
     // magnitude, so a sampled vertex or a projection may be non-finite.  Such a scene takes wave_count_hits_plain: no
     // pretest (their proofs assume numbers) and the axis test that restores minmax_element's behaviour on a NaN first
@@ -83,6 +86,10 @@ C2D_DEV Scene make_scene_values(float robot_w, float robot_h, float px, float py
     sc.hw = pose.width / 2;                                                    // ccp.cu:128
     sc.hh = pose.height / 2;
     sc.sx = sd.x; sc.sy = sd.y; sc.st = sd.theta; sc.sw = sd.width; sc.sh = sd.height;
+    sc.mrx = px; sc.mry = py; sc.mcr = c; sc.msr = s;
+    sc.mhw = __builtin_fabsf(robot_w / 2);
+    sc.mhh = __builtin_fabsf(robot_h / 2);
+    sc.margin = __builtin_inff();
 
     // ---- certain-separation pretest ------------------------------------------------
     // Every vertex of a sampled obstacle is  centre + w  with centre = (dx, dy) and
@@ -156,6 +163,17 @@ C2D_DEV Scene make_scene_values(float robot_w, float robot_h, float px, float py
         if (L > 0.0f && G > 0.0f) R0 = __builtin_fmaxf(R0, L / G);
         // G == 0 (sigma_x = sigma_y = 0) leaves T_i = 0: centre_pretest itself decides that case
     }
+    // ---- margin of the closed-form test (derivation at model_gap).  C bounds every coordinate, every centre offset plus
+    // extent sum of the robot and of any sampled obstacle; h is the smallest half extent any of the eight edges can have
+    {
+        const float C = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(px), __builtin_fabsf(py)) + (sc.mhw + sc.mhh),
+                                        kNormalMax * __builtin_fmaxf(__builtin_fabsf(sc.sx), __builtin_fabsf(sc.sy)) + (hxm + hym)) * (1.0f + 0x1p-10f);
+        const float hx_lo = __builtin_fabsf(sc.hw) - 0.5f * kNormalMax * __builtin_fabsf(sc.sw) * (1.0f + 0x1p-10f);
+        const float hy_lo = __builtin_fabsf(sc.hh) - 0.5f * kNormalMax * __builtin_fabsf(sc.sh) * (1.0f + 0x1p-10f);
+        const float h = __builtin_fminf(__builtin_fminf(sc.mhw, sc.mhh), __builtin_fminf(hx_lo, hy_lo));
+        if (h >= 1e-12f && C < 1e15f)  // (false for a NaN)
+            sc.margin = (64.0f + 20.0f * (C / h)) * (0x1p-24f * C) * (1.0f + 0x1p-10f);
+    }
     sc.use_x0 = false;
     sc.x0 = 0xffffffffu;
     {
@@ -203,6 +221,8 @@ C2D_DEV Scene make_scene(float robot_w, float robot_h, float px, float py, const
         sc.skip_lo[i] = to_sgpr(sc.skip_lo[i]); sc.skip_hi[i] = to_sgpr(sc.skip_hi[i]);
     }
     sc.skip_c2 = to_sgpr(sc.skip_c2); sc.skip_c3 = to_sgpr(sc.skip_c3);
+    sc.mrx = to_sgpr(sc.mrx); sc.mry = to_sgpr(sc.mry); sc.mcr = to_sgpr(sc.mcr); sc.msr = to_sgpr(sc.msr);
+    sc.mhw = to_sgpr(sc.mhw); sc.mhh = to_sgpr(sc.mhh); sc.margin = to_sgpr(sc.margin);
     sc.x0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sc.x0);
 #endif
     return sc;
@@ -233,12 +253,12 @@ C2D_DEV void sample_centre(const Scene& sc, uint32_t radius_word, uint32_t angle
     dy = n1 * sc.sy;
 }
 
-C2D_DEV void sample_obstacle(const Scene& sc, uint32_t radius_word, uint32_t angle_word, float dx, float dy, uint64_t seed,
-                             uint64_t scene_id, uint64_t sample, float (&o)[8], float& dt)
+C2D_DEV void sample_shape(const Scene& sc, uint32_t radius_word, uint32_t angle_word, uint64_t seed, uint64_t scene_id, uint64_t sample,
+                          float& hx, float& hy, float& s, float& c)
 {
     float n2, n3;
     box_muller(radius_word, angle_word, n2, n3);
-    dt = n2 * sc.st;
+    const float dt = n2 * sc.st;
     const float dw = n3 * sc.sw;
     float dh = 0.0f;
     if (sc.sh != 0.0f) {  // wave-uniform
@@ -249,10 +269,9 @@ C2D_DEV void sample_obstacle(const Scene& sc, uint32_t radius_word, uint32_t ang
         dh = n4 * sc.sh;
     }
     // r_out = r_in + create_rect(dw, dh): half extents add (utils.cu:152-155)
-    const float hx = sc.hw + dw / 2, hy = sc.hh + dh / 2;
-    float s, c;
+    hx = sc.hw + dw / 2;
+    hy = sc.hh + dh / 2;
     sincos_(dt, s, c);
-    rect_from_half_extents(hx, hy, c, s, dx, dy, o);  // utils.cu:156
 }
 
 // convex_collide(robot, obstacle) (utils.cu:159-184).  All eight axes are part
@@ -346,7 +365,7 @@ C2D_DEV unsigned long long obstacle_axes_survivors(const Scene& sc, const float 
 }
 #endif
 
-// lanes whose sample collides (no axis separates it): convex_collide(robot, obstacle), utils.cu:159-184.
+// those of `lanes` whose sample collides (no axis separates it): convex_collide(robot, obstacle), utils.cu:159-184.
 //
 // All eight axes are part of the reference's result.  Two kinds of work are left out here, neither of which can change a
 // lane's answer:
@@ -363,9 +382,8 @@ C2D_DEV unsigned long long obstacle_axes_survivors(const Scene& sc, const float 
 //    whenever an undecided lane's overlap on axis a is thinner than that (a few waves in a hundred on the bench scenes).
 // Validation builds (C2D_MC_NO_AXIS_SKIP, part of `make lib-nopretest`) evaluate every axis; tests/test_gpu_fullsize.py
 // compares the two builds on whole workloads.
-C2D_DEV unsigned long long sample_collides_mask(const Scene& sc, const float (&o)[8])
+C2D_DEV unsigned long long sample_collides_mask(const Scene& sc, const float (&o)[8], unsigned long long lanes)
 {
-    const unsigned long long lanes = wave_lanes();
 #ifdef C2D_MC_NO_AXIS_SKIP
     unsigned long long sep = 0;
 #pragma unroll
@@ -412,12 +430,10 @@ constexpr int kCandSlots = 64 + 256 * C2D_MC_ILP;  // < 64 left over + every sam
 //    candidates (radius word, offset) wait in `cand` for their angle word / Box-Muller / centre pretest, the undecided
 //    ones among them in `und` for the full evaluation.  Each of these later stages draws the block it needs per sample.
 struct WaveQueue {
-    // The scene fields that only the full evaluation reads (park_scene / load_eval): 24 floats, read back as six
-    // broadcast ds_read_b128 per 64 evaluated samples instead of living in two dozen VGPRs through every sample loop
-    float4 ev[6];
-    // Survivors of the robot's axes waiting for the obstacle's axes (evaluate_samples): centre and rotation angle, from which
-    // the obstacle is rebuilt.  < 64 left over + at most 63 pushed by a pass.
-    float sv_dx[128], sv_dy[128], sv_dt[128];
+    // Scene fields parked by lane 0 and read back as broadcast ds_read_b128 where they are used, instead of living in VGPRs
+    // through every sample loop: ev[0..2] what every full evaluation reads (park_scene / load_eval; the adaptive kernels only),
+    // ev[3..6] what only the vertex arithmetic behind a thin closed-form result reads (park_exact / load_exact; every kernel)
+    float4 ev[7];
     union {
         struct {
             float4 cw[kQueueSlots];      // dx, dy, bits(radius word 2), bits(angle word 2)
@@ -436,132 +452,146 @@ struct WaveQueue {
     };
 };
 
-// Used by the adaptive kernels, whose register budget (80 VGPRs for six waves per SIMD) the full scene does not fit: with
-// the scene in registers they spill 17-21 dwords and reload some inside the sample loops; parked, no scratch access is left
-// in any sample loop (profiles/r03_mc_isa.md).  The times are the same within 0.5 % (config-4 shard 383 ms either way,
-// reference-default batch 39.4 vs 40.0 ms): the spills were harmless, the parked form is simply the one without them.
-// mc_pair_kernel (92 VGPRs at five waves, nothing spilled) keeps the scene in registers: every sample of the config-3 scene
-// is evaluated in full, and the six LDS reads per evaluation cost it 3 % (0.547 -> 0.564 ms per 1e8 samples).
-// Splits a scene: the fields of the per-sample path (sigma_x, sigma_y, the centre pretest, the radius threshold) stay in
-// registers; the ones only a full evaluation needs (robot, obstacle extents, the other sigmas, the parallel-axis
-// certificates) are parked in the wave's LDS by lane 0 and come back through load_eval right before they are used.
-// Returns the scene with the parked fields cleared, so that their registers are free in between.
-C2D_DEV Scene park_scene(const Scene& sc, WaveQueue& q)
+// ---- parking.  The scene is wave-uniform, yet each of its fields occupies a VGPR (no scalar floating point on gfx950).
+// Two groups of fields leave the registers:
+//  * the EXACT group (robot vertices, parallel-axis certificates) is read only by the vertex arithmetic behind a thin
+//    closed-form result (evaluate_samples), about one evaluation pass in a hundred: parked by every kernel (park_exact);
+//  * the EVAL group (the other sigmas, the obstacle's extents, the robot's model) is read by every full evaluation: parked by
+//    the adaptive kernels, whose 80-VGPR budget (six waves per SIMD) the scene does not fit — with it in registers they spilled
+//    17-21 dwords and reloaded some inside the sample loops (profiles/r03_mc_isa.md) — and kept in registers by mc_pair_kernel,
+//    where every sample of the config-3 scene is evaluated and the extra LDS reads cost 3 %.
+// The functions return the scene with the parked fields cleared, so that their registers are free in between.
+C2D_DEV void wave_lds_sync()
 {
-    if ((threadIdx.x & 63) == 0) {
-        q.ev[0] = make_float4(sc.robot[0], sc.robot[1], sc.robot[2], sc.robot[3]);
-        q.ev[1] = make_float4(sc.robot[4], sc.robot[5], sc.robot[6], sc.robot[7]);
-        q.ev[2] = make_float4(sc.skip_lo[0], sc.skip_lo[1], sc.skip_hi[0], sc.skip_hi[1]);
-        q.ev[3] = make_float4(sc.skip_c2, sc.skip_c3, sc.hw, sc.hh);
-        q.ev[4] = make_float4(sc.st, sc.sw, sc.sh, 0.0f);
-    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    Scene h;
+}
+
+C2D_DEV Scene park_exact(const Scene& sc, WaveQueue& q)
+{
+    if ((threadIdx.x & 63) == 0) {
+        q.ev[3] = make_float4(sc.robot[0], sc.robot[1], sc.robot[2], sc.robot[3]);
+        q.ev[4] = make_float4(sc.robot[4], sc.robot[5], sc.robot[6], sc.robot[7]);
+        q.ev[5] = make_float4(sc.skip_lo[0], sc.skip_lo[1], sc.skip_hi[0], sc.skip_hi[1]);
+        q.ev[6] = make_float4(sc.skip_c2, sc.skip_c3, 0.0f, 0.0f);
+    }
+    wave_lds_sync();
+    Scene h = sc;
 #pragma unroll
     for (int k = 0; k < 8; k++) h.robot[k] = 0.0f;
-    h.hw = h.hh = h.st = h.sw = h.sh = 0.0f;
     h.skip_c2 = h.skip_c3 = 0.0f;
-    h.sx = sc.sx;
-    h.sy = sc.sy;
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-        h.pax[i] = sc.pax[i]; h.pay[i] = sc.pay[i]; h.plo[i] = sc.plo[i]; h.phi[i] = sc.phi[i];
-        h.skip_lo[i] = h.skip_hi[i] = 0.0f;
-    }
-    h.x0 = sc.x0;
-    h.use_x0 = sc.use_x0;
+    for (int i = 0; i < 2; i++) h.skip_lo[i] = h.skip_hi[i] = 0.0f;
     return h;
 }
 
-// the scene with its parked fields read back (the compiler barrier keeps the reads inside the loop they are used in)
+C2D_DEV Scene park_scene(const Scene& sc, WaveQueue& q)
+{
+    if ((threadIdx.x & 63) == 0) {
+        q.ev[0] = make_float4(sc.st, sc.sw, sc.sh, sc.margin);
+        q.ev[1] = make_float4(sc.hw, sc.hh, sc.mhw, sc.mhh);
+        q.ev[2] = make_float4(sc.mrx, sc.mry, sc.mcr, sc.msr);
+    }
+    Scene h = park_exact(sc, q);
+    h.hw = h.hh = h.st = h.sw = h.sh = 0.0f;
+    h.mrx = h.mry = h.mcr = h.msr = h.mhw = h.mhh = h.margin = 0.0f;
+    return h;
+}
+
+// the scene with its EVAL group read back (the compiler barrier keeps the reads inside the loop they are used in)
 template <bool PARKED>
 C2D_DEV Scene load_eval(const Scene& hot, const WaveQueue& q)
 {
     if constexpr (!PARKED) return hot;
     asm volatile("" ::: "memory");
     Scene sc = hot;
-    const float4 a = q.ev[0], b = q.ev[1], c = q.ev[2], d = q.ev[3], e = q.ev[4];
-    sc.robot[0] = a.x; sc.robot[1] = a.y; sc.robot[2] = a.z; sc.robot[3] = a.w;
-    sc.robot[4] = b.x; sc.robot[5] = b.y; sc.robot[6] = b.z; sc.robot[7] = b.w;
-    sc.skip_lo[0] = c.x; sc.skip_lo[1] = c.y; sc.skip_hi[0] = c.z; sc.skip_hi[1] = c.w;
-    sc.skip_c2 = d.x; sc.skip_c3 = d.y; sc.hw = d.z; sc.hh = d.w;
-    sc.st = e.x; sc.sw = e.y; sc.sh = e.z;
+    const float4 a = q.ev[0], b = q.ev[1], c = q.ev[2];
+    sc.st = a.x; sc.sw = a.y; sc.sh = a.z; sc.margin = a.w;
+    sc.hw = b.x; sc.hh = b.y; sc.mhw = b.z; sc.mhh = b.w;
+    sc.mrx = c.x; sc.mry = c.y; sc.mcr = c.z; sc.msr = c.w;
     return sc;
 }
 
-// ---- the full evaluation of up to 64 samples, in two stages with a compaction in between ------------------------------
-// On the dataset workloads most samples that reach the full evaluation are misses after all (config-4 shard: 5.7 % of the
-// drawn samples are evaluated, 0.74 % hit; reference-default batch: 12 % and 0.8 %; tests/tools/mc_stats.py), and the
-// robot's axes — whose robot-side interval is a scene constant — separate nearly all of those.  So a pass evaluates the
-// robot's axes for its 64 samples, and only the SURVIVORS go on to the obstacle's axes (the dearer half: both rectangles are
-// projected per sample): their centre and rotation angle are pushed to a third per-wave queue, and when 64 have gathered the
-// obstacle is rebuilt for them (same floats: sincos of the same angle, the same products) and its axes evaluated on 64 busy
-// lanes.  When most lanes of a pass survive (a scene with p ~ 0.5: config 3) the obstacle's axes are evaluated in place
-// instead, as before.  Shapes with width / height noise keep their extents per sample and are always evaluated in place.
-// The result is the same OR over the same eight axes in another order.  Measured: see DESIGN.md §5.
-#ifndef C2D_MC_IN_PLACE_FROM
-#define C2D_MC_IN_PLACE_FROM 40  // survivors among a pass's 64 samples from which the obstacle's axes run in place
-#endif
-
-// the obstacle's axes for `take` queued survivors (take <= 64, the last ones pushed)
-C2D_DEV uint32_t drain_survivors(const Scene& ev, WaveQueue& wq, uint32_t& sn, uint32_t take)
+// ... and with its EXACT group
+C2D_DEV Scene load_exact(const Scene& ev, const WaveQueue& q)
 {
-    const uint32_t lane = threadIdx.x & 63;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const uint32_t src = sn - take + (lane < take ? lane : 0);
-    const float dx = wq.sv_dx[src], dy = wq.sv_dy[src], dt = wq.sv_dt[src];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    sn -= take;
-    float s, c, o[8];
-    sincos_(dt, s, c);
-    rect_from_half_extents(ev.hw, ev.hh, c, s, dx, dy, o);  // (fixed shape: dw = dh = +-0, the half extents are the scene's)
-    const unsigned long long live_m = take >= 64 ? ~0ull : (1ull << take) - 1;
-#ifdef C2D_MC_NO_AXIS_SKIP
-    (void)live_m;
-    return 0;  // (never called in the validation build)
-#else
-    return (uint32_t)__popcll(obstacle_axes_survivors(ev, o, live_m));
-#endif
+    asm volatile("" ::: "memory");
+    Scene sc = ev;
+    const float4 a = q.ev[3], b = q.ev[4], c = q.ev[5], d = q.ev[6];
+    sc.robot[0] = a.x; sc.robot[1] = a.y; sc.robot[2] = a.z; sc.robot[3] = a.w;
+    sc.robot[4] = b.x; sc.robot[5] = b.y; sc.robot[6] = b.z; sc.robot[7] = b.w;
+    sc.skip_lo[0] = c.x; sc.skip_lo[1] = c.y; sc.skip_hi[0] = c.z; sc.skip_hi[1] = c.w;
+    sc.skip_c2 = d.x; sc.skip_c3 = d.y;
+    return sc;
 }
 
-// hits among the (up to 64, mask live_m) samples of a pass that are decided by this call; survivors may stay queued
+// ---- the closed-form test of a full evaluation -------------------------------------------------------------------------------
+// Both rectangles are BUILT from a centre, a rotation (c, s) and half extents (rect_from_half_extents), so the reference's
+// eight axes are, up to rounding, the four directions e of the two frames, each twice, and convex_collide's answer on an axis
+// pair is the sign of the closed-form gap
+//     G_e = |e . (centre_o - centre_r)| - |e . U_r| - |e . V_r| - |e . U_o| - |e . V_o|,      U = hx (c, s), V = hy (-s, c)
+// whenever |G_e| exceeds what rounding can move.  Take the real rectangles M with exactly these centres and half axes (the
+// floats c, s, hx, hy read as reals).  With u = 2^-24, C >= every |centre coordinate| + |hx| + |hy| and h = |half extent| of
+// the edge in question:
+//   * a computed vertex coordinate is within 3uC of M's (two products, their sum, the translation);
+//   * a computed edge vector a^ = v_k+1 - v_k is within 8uC per component of M's edge n = +-2U or +-2V, so |a^ - n|_1 <= 16uC;
+//   * a computed projection p^(v^) = fl(fl(a^x v^x) + fl(a^y v^y)) is within E = 5.1u |a^|_1 C + 16.1u C^2 of n . v
+//     (its two roundings, the edge error times the coordinates, the vertex error times the edge);
+//   * hence each of the four interval ends of utils.cu:176-177 is within E of M's, and the two overlaps of utils.cu:178 within
+//     2E of M's, whose smaller one is exactly -G(n) = -2h G_e: |G_e| > E / h fixes both comparisons on that edge AND on
+//     the opposite edge (same n up to sign), E / h <= 14.5uC + 16.1u C^2 / h;
+//   * G_e as evaluated below (fma where the choice is ours) is within 20uC of the real G_e, and writing |e . U| = h for the
+//     rectangle's own edge instead of h (c^2 + s^2) costs at most 16uC (|c^2 + s^2 - 1| <= 2^-20 for sincos_).
+// So with margin = (64 + 20 C / h_min) u C (make_scene; >= 1.24 x the sum above): max_e G_e > margin proves that the reference
+// finds a separating axis, max_e G_e < -margin proves that it finds none, and anything in between — a NaN too — is "thin" and is
+// evaluated with the reference's vertex arithmetic.  h_min >= 1e-12 keeps every product far above the subnormals.  Checked
+// against the oracle on random and on razor-thin pairs in tests/test_oracle.py (a numpy restatement of this function) and by
+// every Monte-Carlo test on the GPU; `make lib-nopretest` builds the kernels without it.
+C2D_DEV float model_gap(const Scene& ev, float dx, float dy, float c, float s, float hx, float hy)
+{
+    const float q1 = fma_(ev.mcr, c, ev.msr * s);       // cos, sin of the angle between the frames
+    const float q2 = fma_(ev.mcr, s, -(ev.msr * c));
+    const float ex = dx - ev.mrx, ey = dy - ev.mry;
+    const float t1 = fma_(ev.mcr, ex, ev.msr * ey);     // centre offset along the robot's axes ...
+    const float t2 = fma_(ev.mcr, ey, -(ev.msr * ex));
+    const float t3 = fma_(c, ex, s * ey);               // ... and along the obstacle's
+    const float t4 = fma_(c, ey, -(s * ex));
+    const float a1 = __builtin_fabsf(q1), a2 = __builtin_fabsf(q2), ax = __builtin_fabsf(hx), ay = __builtin_fabsf(hy);
+    const float g1 = __builtin_fabsf(t1) - fma_(ax, a1, fma_(ay, a2, ev.mhw));
+    const float g2 = __builtin_fabsf(t2) - fma_(ax, a2, fma_(ay, a1, ev.mhh));
+    const float g3 = __builtin_fabsf(t3) - fma_(ev.mhw, a1, fma_(ev.mhh, a2, ax));
+    const float g4 = __builtin_fabsf(t4) - fma_(ev.mhw, a2, fma_(ev.mhh, a1, ay));
+    return __builtin_fmaxf(__builtin_fmaxf(g1, g2), __builtin_fmaxf(g3, g4));
+}
+
+// hits among the (up to 64, mask live_m) samples of a pass: second Box-Muller pair, rotation, the closed-form test, and for a
+// pass with a thin sample the reference's vertex arithmetic (axes 0, 1 of each rectangle with the parallel-axis certificates,
+// sample_collides_mask) on the thin lanes
 template <bool PARKED>
-C2D_DEV uint32_t evaluate_samples(const Scene& sc, WaveQueue& wq, uint32_t& sn, uint32_t w2r, uint32_t w2a, float dx, float dy, uint64_t seed,
+C2D_DEV uint32_t evaluate_samples(const Scene& sc, WaveQueue& wq, uint32_t w2r, uint32_t w2a, float dx, float dy, uint64_t seed,
                                   uint64_t scene_id, uint64_t sample, unsigned long long live_m)
 {
     const Scene ev = load_eval<PARKED>(sc, wq);
     C2D_MC_STAT(5, __popcll(live_m));
-    float o[8], dt;
-    sample_obstacle(ev, w2r, w2a, dx, dy, seed, scene_id, sample, o, dt);
-#ifdef C2D_MC_NO_AXIS_SKIP
-    return (uint32_t)__popcll(sample_collides_mask(ev, o) & live_m);
-#else
-    const unsigned long long surv = robot_axes_survivors(ev, o, live_m);
-    if (surv == 0ull) return 0;
-    // mc_pair_kernel (PARKED == false: one scene, every wave on the same scene) always goes on in place: on the config-3 scene
-    // 85 % of the evaluated samples survive the robot's axes, and the queue's bookkeeping alone costs it 2 % (0.545 -> 0.557 ms)
-    if constexpr (!PARKED) return (uint32_t)__popcll(obstacle_axes_survivors(ev, o, surv));
-    const uint32_t ns = (uint32_t)__popcll(surv);
-    C2D_MC_STAT(8, ns);
-    if (ns >= (uint32_t)C2D_MC_IN_PLACE_FROM || ev.sw != 0.0f || ev.sh != 0.0f) return (uint32_t)__popcll(obstacle_axes_survivors(ev, o, surv));
-    const uint32_t lane = threadIdx.x & 63;
-    if ((surv >> lane) & 1ull) {
-        const uint32_t slot = sn + __builtin_amdgcn_mbcnt_hi((uint32_t)(surv >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)surv, 0u));
-        wq.sv_dx[slot] = dx;
-        wq.sv_dy[slot] = dy;
-        wq.sv_dt[slot] = dt;
+    float hx, hy, s, c;
+    sample_shape(ev, w2r, w2a, seed, scene_id, sample, hx, hy, s, c);
+    uint32_t hits = 0;
+    unsigned long long thin = live_m;
+#ifndef C2D_MC_NO_MODEL_TEST
+    {
+        const float g = model_gap(ev, dx, dy, c, s, hx, hy);
+        const unsigned long long col = __builtin_amdgcn_ballot_w64(g < -ev.margin), sep = __builtin_amdgcn_ballot_w64(g > ev.margin);
+        hits = (uint32_t)__popcll(col & live_m);
+        thin = live_m & ~(col | sep);
+        if (thin == 0ull) return hits;
     }
-    sn += ns;
-    C2D_MC_STAT(9, ns);
-    if (sn < 64) return 0;
-    return drain_survivors(ev, wq, sn, 64);
 #endif
+    C2D_MC_STAT(8, 1);
+    const Scene ex = load_exact(ev, wq);
+    float o[8];
+    rect_from_half_extents(hx, hy, c, s, dx, dy, o);  // utils.cu:156
+    return hits + (uint32_t)__popcll(sample_collides_mask(ex, o, thin));
 }
 
 #ifndef C2D_MC_PARK_ADAPTIVE
@@ -571,7 +601,7 @@ constexpr bool kParkAdaptive = C2D_MC_PARK_ADAPTIVE != 0;
 C2D_DEV Scene adaptive_scene(const Scene& sc, WaveQueue& q)
 {
     if constexpr (kParkAdaptive) return park_scene(sc, q);
-    else return sc;
+    else return park_exact(sc, q);
 }
 
 // ---- NEAR: hits among samples [begin, begin + count) of one scene, computed by one wave.  A lane owns one GROUP of four
@@ -590,7 +620,6 @@ C2D_DEV uint32_t wave_count_hits_near(const Scene& sc, uint64_t seed, uint64_t s
     auto& q = wq.near;
     const uint32_t lane = threadIdx.x & 63;
     uint32_t hits = 0;    // wave-uniform (scalar) accumulator
-    uint32_t sn = 0;      // survivors of the robot's axes waiting for the obstacle's (evaluate_samples)
     uint32_t qn = 0;      // queued samples (wave-uniform)
     uint32_t dense = 0;   // sub-iterations to evaluate in place after the pretest ruled nothing out
     // (count < 2^31 — the callers cut work into far smaller chunks — keeps every offset below in 32 bits)
@@ -713,12 +742,9 @@ C2D_DEV uint32_t wave_count_hits_near(const Scene& sc, uint64_t seed, uint64_t s
                 w2r = __float_as_uint(e.z);
                 w2a = __float_as_uint(e.w);
             }
-            hits += evaluate_samples<PARKED>(sc, wq, sn, w2r, w2a, dx, dy, seed, scene_id, begin + sidx, live_m);
+            hits += evaluate_samples<PARKED>(sc, wq, w2r, w2a, dx, dy, seed, scene_id, begin + sidx, live_m);
             if (flush) break;
         }
-    }
-    if constexpr (PARKED) {
-        if (sn) hits += drain_survivors(load_eval<PARKED>(sc, wq), wq, sn, sn);  // (fewer than 64 are left)
     }
     return hits;
 }
@@ -738,7 +764,6 @@ C2D_DEV uint32_t wave_count_hits_far(const Scene& sc, uint64_t seed, uint64_t sc
     auto& q = wq.far;
     const uint32_t lane = threadIdx.x & 63;
     uint32_t hits = 0, cn = 0, un = 0;  // wave-uniform: hits, queued candidates, queued undecided samples
-    uint32_t sn = 0;                    // survivors of the robot's axes waiting for the obstacle's (evaluate_samples)
     const uint64_t g0 = begin >> 2;
     const uint32_t base = (uint32_t)(begin & 3);
     const uint32_t end_pos = base + count;
@@ -843,12 +868,9 @@ C2D_DEV uint32_t wave_count_hits_far(const Scene& sc, uint64_t seed, uint64_t sc
             const uint64_t s = begin + sidx;
             const U4 pb = philox_draw_block(seed, scene_id, s >> 2, 2u + ((uint32_t)(s >> 1) & 1u));
             const bool odd = (s & 1) != 0;
-            hits += evaluate_samples<PARKED>(sc, wq, sn, odd ? pb.z : pb.x, odd ? pb.w : pb.y, c.x, c.y, seed, scene_id, s, live_m);
+            hits += evaluate_samples<PARKED>(sc, wq, odd ? pb.z : pb.x, odd ? pb.w : pb.y, c.x, c.y, seed, scene_id, s, live_m);
         }
         if (drained && cn == 0 && un == 0) break;
-    }
-    if constexpr (PARKED) {
-        if (sn) hits += drain_survivors(load_eval<PARKED>(sc, wq), wq, sn, sn);  // (fewer than 64 are left)
     }
     return hits;
 }
@@ -871,9 +893,10 @@ C2D_DEV uint32_t wave_count_hits_plain(const Scene& sc, uint64_t seed, uint64_t 
         const U4 b2 = philox_draw_block(seed, scene_id, s >> 2, 2u + (j >> 1));
         float dx, dy, o[8];
         sample_centre(sc, u4_word(b0, (int)j), u4_word(b1, (int)j), dx, dy);
-        const Scene ev = load_eval<PARKED>(sc, wq);
-        float dt_unused;
-        sample_obstacle(ev, (j & 1u) ? b2.z : b2.x, (j & 1u) ? b2.w : b2.y, dx, dy, seed, scene_id, s, o, dt_unused);
+        const Scene ev = load_exact(load_eval<PARKED>(sc, wq), wq);
+        float hx, hy, sn, cs;
+        sample_shape(ev, (j & 1u) ? b2.z : b2.x, (j & 1u) ? b2.w : b2.y, seed, scene_id, s, hx, hy, sn, cs);
+        rect_from_half_extents(hx, hy, cs, sn, dx, dy, o);  // utils.cu:156
         hits += (uint32_t)__popcll(__ballot(live && rect_collide(ev.robot, o)));
     }
     return hits;
@@ -916,7 +939,7 @@ __global__ __launch_bounds__(kMcBlock, C2D_MC_PAIR_WAVES) void mc_pair_kernel(Pa
 {
     __shared__ WaveQueue s_queue[kWavesPerBlock];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const Scene sc = make_scene(A.robot_w, A.robot_h, A.px, A.py, A.pose, A.sd);  // (not parked: see park_scene)
+    const Scene sc = park_exact(make_scene(A.robot_w, A.robot_h, A.px, A.py, A.pose, A.sd), s_queue[wave]);  // (EVAL group in registers: see park_scene)
     const uint64_t n_chunks = (A.n_samples + A.chunk - 1) / A.chunk;
     unsigned long long total = 0;
     for (uint64_t ch = (uint64_t)blockIdx.x * kWavesPerBlock + wave; ch < n_chunks; ch += (uint64_t)gridDim.x * kWavesPerBlock) {

@@ -400,3 +400,87 @@ def test_parallel_axis_certificate_error_bound(oracle, wl):
                         assert (e <= bound).all(), (seed, i, k)
                         worst = max(worst, float(np.where(bound > 0, e / np.where(bound > 0, bound, 1), 0).max()))
     assert 0.5 < worst <= 1.0
+
+
+# ---- the closed-form test behind the Monte-Carlo full evaluation and the pose-format pair kernel (c2d_mc.hip model_gap,
+# c2d_sat.hip): a numpy restatement, decision by decision against the oracle's convex_collide
+def _fma32(a, b, c):
+    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+
+
+def closed_form_gap(oracle, x1, y1, w1, h1, t1, x2, y2, w2, h2, t2):
+    """-> (gap, margin): float32 restatement of model_gap for rectangle 1 = 'robot', rectangle 2 = 'obstacle', with the margin
+    (64 + 20 C / h_min) u C taken per pair"""
+    F = np.float32
+    s1, c1 = oracle.sincosf(t1)
+    s2, c2 = oracle.sincosf(t2)
+    hw, hh, hx, hy = np.abs(w1 / F(2)), np.abs(h1 / F(2)), np.abs(w2 / F(2)), np.abs(h2 / F(2))
+    q1 = _fma32(c1, c2, (s1 * s2).astype(F))
+    q2 = _fma32(c1, s2, -(s1 * c2).astype(F))
+    ex, ey = (x2 - x1).astype(F), (y2 - y1).astype(F)
+    t1_ = _fma32(c1, ex, (s1 * ey).astype(F))
+    t2_ = _fma32(c1, ey, -(s1 * ex).astype(F))
+    t3_ = _fma32(c2, ex, (s2 * ey).astype(F))
+    t4_ = _fma32(c2, ey, -(s2 * ex).astype(F))
+    a1, a2 = np.abs(q1), np.abs(q2)
+    g1 = (np.abs(t1_) - _fma32(hx, a1, _fma32(hy, a2, hw))).astype(F)
+    g2 = (np.abs(t2_) - _fma32(hx, a2, _fma32(hy, a1, hh))).astype(F)
+    g3 = (np.abs(t3_) - _fma32(hw, a1, _fma32(hh, a2, hx))).astype(F)
+    g4 = (np.abs(t4_) - _fma32(hw, a2, _fma32(hh, a1, hy))).astype(F)
+    g = np.maximum(np.maximum(g1, g2), np.maximum(g3, g4))
+    C = (np.maximum(np.maximum(np.abs(x1), np.abs(y1)) + (hw + hh), np.maximum(np.abs(x2), np.abs(y2)) + (hx + hy)) * F(1 + 2.0 ** -10)).astype(F)
+    h = np.minimum(np.minimum(hw, hh), np.minimum(hx, hy))
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        margin = ((F(64) + F(20) * (C / h)) * (F(2.0 ** -24) * C) * F(1 + 2.0 ** -10)).astype(F)
+    margin = np.where((h >= F(1e-12)) & (C < F(1e15)), margin, np.float32(np.inf))
+    return g, margin
+
+
+def _closed_form_against_oracle(oracle, poses):
+    F = np.float32
+    poses = [np.asarray(p, F) for p in poses]
+    g, m = closed_form_gap(oracle, *poses)
+    ref, _ = oracle.sat_rect_pairs_pose(np.stack(poses))
+    sep, col = g > m, g < -m
+    assert not (sep & (ref != 0)).any(), "closed form says separated, the oracle says the pair collides"
+    assert not (col & (ref == 0)).any(), "closed form says colliding, the oracle finds a separating axis"
+    return float(1.0 - (sep | col).mean())
+
+
+def test_closed_form_gap_decides_like_the_oracle_on_random_pairs(oracle):
+    rng = np.random.default_rng(11)
+    n = 60_000
+    for pos, lo, hi, scale in ((8, 0.1, 5, 1), (8, 0.1, 5, 1e-3), (8, 0.1, 5, 1e4), (100, 0.1, 5, 1), (1, 0.5, 2, 1), (1000, 0.01, 1, 1), (3, 3, 6, 1), (2, 1e-3, 4, 1)):
+        xy = [rng.uniform(-pos, pos, n) * scale for _ in range(4)]
+        wh = [rng.uniform(lo, hi, n) * scale for _ in range(4)]
+        th = [rng.uniform(-7, 7, n) for _ in range(2)]
+        thin = _closed_form_against_oracle(oracle, (xy[0], xy[1], wh[0], wh[1], th[0], xy[2], xy[3], wh[2], wh[3], th[1]))
+        assert thin < (0.2 if pos >= 100 or lo < 0.01 else 0.02), (pos, lo, hi, scale, thin)
+
+
+def test_closed_form_gap_on_razor_thin_pairs(oracle):
+    """Pairs built to touch: the second rectangle's centre sits along an axis of either frame at exactly the distance where that
+    axis' gap is zero, moved by a few parts in 1e-7 .. 1e-3.  Every decision the closed form takes must be the oracle's."""
+    rng = np.random.default_rng(12)
+    n = 40_000
+    F = np.float32
+    for scale, off in ((1.0, 0.0), (1.0, 50.0), (1e-4, 0.0), (1e3, 0.0)):
+        w1, h1, w2, h2 = [(rng.uniform(0.2, 4, n) * scale).astype(F) for _ in range(4)]
+        t1 = rng.uniform(-3.2, 3.2, n).astype(F)
+        t2 = np.where(rng.random(n) < 0.3, t1 + rng.choice([0.0, np.pi / 2, np.pi], n), rng.uniform(-3.2, 3.2, n)).astype(F)
+        x1, y1 = [(rng.uniform(-1, 1, n) * scale + off * scale).astype(F) for _ in range(2)]
+        s1, c1 = [v.astype(np.float64) for v in oracle.sincosf(t1)]
+        s2, c2 = [v.astype(np.float64) for v in oracle.sincosf(t2)]
+        which = rng.integers(0, 4, n)
+        ex = np.choose(which, [c1, -s1, c2, -s2])
+        ey = np.choose(which, [s1, c1, s2, c2])
+        hw, hh, hx, hy = [np.abs(v.astype(np.float64)) / 2 for v in (w1, h1, w2, h2)]
+        ext = (hw * np.abs(ex * c1 + ey * s1) + hh * np.abs(-ex * s1 + ey * c1) + hx * np.abs(ex * c2 + ey * s2) + hy * np.abs(-ex * s2 + ey * c2))
+        rel = rng.choice([0.0, 1e-7, -1e-7, 3e-7, -3e-7, 1e-6, -1e-6, 1e-5, -1e-5, 1e-4, -1e-4, 1e-3, -1e-3], n)
+        dist = ext * (1 + rel) / (ex * ex + ey * ey)
+        sign = rng.choice([-1.0, 1.0], n)
+        lateral = rng.uniform(-0.3, 0.3, n) * scale   # along the axis' normal: does not change this axis' gap
+        x2 = (x1 + sign * dist * ex - lateral * ey).astype(F)
+        y2 = (y1 + sign * dist * ey + lateral * ex).astype(F)
+        thin = _closed_form_against_oracle(oracle, (x1, y1, w1, h1, t1, x2, y2, w2, h2, t2))
+        assert thin > 0.01, "the construction is meant to land inside the margin often"
