@@ -1034,12 +1034,14 @@ __global__ void mc_scenes_init_kernel(AdaptiveState* state, uint32_t n_scenes)
     *state = init;
 }
 
-// 6 waves per SIMD (80 VGPRs; a dozen dwords spill, all but two reloads outside the sample loops) instead of the 5 the
-// compiler would take: the certain-miss path is a chain of dependent Philox multiplies, and the sixth wave is worth 3-5 % on
-// the config-4 workload (412 -> 400 ms per 4e6 data points with the group-of-four draw layout, 806.7 -> 765.5 ms before it)
-// and on the reference-default batch; 7 waves (72 VGPRs) give nothing more.
+// 7 waves per SIMD (72 VGPRs) instead of the 5 the compiler would take: the certain-miss path is a chain of dependent Philox
+// multiplies, and more waves hide it.  The sixth wave was worth 3-5 % on the config-4 workload (412 -> 400 ms per 4e6 data
+// points) and on the reference-default batch; since the closed-form evaluation (model_gap) shortened the live ranges of the
+// full evaluation the seventh is worth another 3 % (336 -> 325 ms, 33.1 -> 32.5 ms; 5 waves: 349 ms, 8 waves spill inside the
+// sample loops).  At 72 registers 16-17 dwords spill: every one of their stores and reloads sits outside the sample loops, in
+// the per-work-item code (profiles/r03_mc_isa.md lists them with their loop depth).
 #ifndef C2D_MC_ADV_WAVES
-#define C2D_MC_ADV_WAVES 6
+#define C2D_MC_ADV_WAVES 7
 #endif
 template <bool BURST>
 __global__ __launch_bounds__(kMcBlock, C2D_MC_ADV_WAVES) void mc_scenes_advance_kernel(ScenesArgs A)

@@ -248,15 +248,48 @@ __global__ __launch_bounds__(64) void sat_rect_aos_kernel(const float* __restric
 }
 
 // ---- rectangle pairs, pose format (10 planes, 41 B/pair) ------------------------------
-// Same lane mapping as the vertex kernel (VEC == 4: one float4 per plane, 4 pairs
-// per lane); both rectangles are rebuilt per pair (2 sincos + 2 x 16 ops): 394 VALU
-// instructions per 41 bytes, which makes this format VALU-bound, not HBM-bound.  Measured
-// (profiles/r02_pose_probe.txt, tools/pose_probe.hip): under this kernel the shader clock settles near
-// 1.4 GHz (s_memtime against s_memrealtime), and 61.6e6 wave-instructions x 2 cycles / 1024 SIMDs at that
-// clock IS the 86 us the kernel takes.  A software-pipelined resident-wave form (next group's loads in
-// flight during the evaluation, 2 to 4 waves per SIMD) issues at the same rate and was 3-6 % slower
-// (89-91 us); SLP-packed v_pk_mul_f32 cuts the count to 321 per pair but costs double issue (96 us).
-// The bit-exact 8-axis evaluation fixes the instruction count, so this kernel is at its roof.
+// Same lane mapping as the vertex kernel (VEC == 4: one float4 per plane, 4 pairs per lane).  Rebuilding both rectangles and
+// running the vertex arithmetic costs 294 VALU instructions per 41 bytes (394 before the parallel-axis certificates), which
+// made this format VALU-bound at the clock the chip holds under it (profiles/r02_pose_probe.txt, tools/pose_probe.hip).  A pose
+// pair, however, is two rectangles BUILT from centre, rotation and extents, so the closed-form gap of the Monte-Carlo kernels
+// applies (c2d_mc.hip, model_gap — the derivation and the error budget are there): per frame direction e
+//     G_e = |e . (centre_2 - centre_1)| - sum of the four half axes' |e . U|,
+// and |G_e| h_e > (64 h_e + 20 C) u C (h_e: half extent of the edge along e, C >= |centre coordinates| + half extents, u = 2^-24)
+// fixes the reference's comparisons on the two edges along e.  One separating direction decides "no collision", four
+// overlapping ones decide "collision"; anything else — about one pair in 10^4 on the bench workload, and every pair with a
+// non-finite or out-of-range parameter — is thin, and the wave evaluates that pair slot with the vertex arithmetic
+// (collide_pairs).  Per-direction margins (not one margin from the smallest extent) keep a sliver's large margin on its own axis.
+C2D_DEV bool pose_pair_closed_form(const float (&v)[10], bool& thin)
+{
+    float s1, c1, s2, c2;
+    sincos_(v[4], s1, c1);
+    sincos_(v[9], s2, c2);
+    const float hw = __builtin_fabsf(v[2] / 2), hh = __builtin_fabsf(v[3] / 2), hx = __builtin_fabsf(v[7] / 2), hy = __builtin_fabsf(v[8] / 2);
+    const float q1 = fma_(c1, c2, s1 * s2), q2 = fma_(c1, s2, -(s1 * c2));
+    const float ex = v[5] - v[0], ey = v[6] - v[1];
+    const float t1 = fma_(c1, ex, s1 * ey), t2 = fma_(c1, ey, -(s1 * ex));
+    const float t3 = fma_(c2, ex, s2 * ey), t4 = fma_(c2, ey, -(s2 * ex));
+    const float a1 = __builtin_fabsf(q1), a2 = __builtin_fabsf(q2);
+    const float g1 = __builtin_fabsf(t1) - fma_(hx, a1, fma_(hy, a2, hw));
+    const float g2 = __builtin_fabsf(t2) - fma_(hx, a2, fma_(hy, a1, hh));
+    const float g3 = __builtin_fabsf(t3) - fma_(hw, a1, fma_(hh, a2, hx));
+    const float g4 = __builtin_fabsf(t4) - fma_(hw, a2, fma_(hh, a1, hy));
+    const float C = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])) + (hw + hh),
+                                    __builtin_fmaxf(__builtin_fabsf(v[5]), __builtin_fabsf(v[6])) + (hx + hy)) * (1.0f + 0x1p-10f);
+    const float uc = (0x1p-24f * (1.0f + 0x1p-10f)) * C, k64 = 64.0f * uc, k20 = (20.0f * uc) * C;
+    const float z1 = g1 * hw, z2 = g2 * hh, z3 = g3 * hx, z4 = g4 * hy;
+    const float m1 = fma_(k64, hw, k20), m2 = fma_(k64, hh, k20), m3 = fma_(k64, hx, k20), m4 = fma_(k64, hy, k20);
+    const float over = __builtin_fmaxf(__builtin_fmaxf(z1 - m1, z2 - m2), __builtin_fmaxf(z3 - m3, z4 - m4));   // > 0: some direction separates
+    const float under = __builtin_fmaxf(__builtin_fmaxf(z1 + m1, z2 + m2), __builtin_fmaxf(z3 + m3, z4 + m4));  // < 0: every direction overlaps
+    // the max / min instructions drop a NaN operand, the sum does not: any non-finite parameter makes it non-finite
+    const float all = (g1 + g2) + (g3 + g4);
+    const float hmin = __builtin_fminf(__builtin_fminf(hw, hh), __builtin_fminf(hx, hy));
+    const bool regular = (C < 1e15f) & (hmin >= 1e-12f) & (__builtin_fabsf(all) < 1e37f);
+    const bool sep = over > 0.0f, col = under < 0.0f;
+    thin = !(regular & (sep | col));
+    return col;
+}
+
 C2D_DEV void pose_pair_rects(const float (&v)[10], float (&r1)[8], float (&r2)[8])
 {
     float s, c;
@@ -286,12 +319,25 @@ __global__ __launch_bounds__(BLOCK, (VEC == 4 ? 5 : 1)) void sat_rect_pose_kerne
             f32x4 q[10];
 #pragma unroll
             for (int k = 0; k < 10; k++) q[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P.p[k]) + g);
-            const uint32_t packed = bits_to_bytes4(collide_pairs<4>([&q](int e, auto how, float (&r1)[8], float (&r2)[8]) {
+            uint32_t bits = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
                 float v[10];
 #pragma unroll
-                for (int k = 0; k < 10; k++) v[k] = launder(q[k][e], how);
-                pose_pair_rects(v, r1, r2);
-            }));
+                for (int k = 0; k < 10; k++) v[k] = q[k][e];
+                bool thin;
+                uint32_t hit = pose_pair_closed_form(v, thin) ? 1u : 0u;
+                if (__ballot(thin) != 0ull) {  // this pair slot with the vertex arithmetic, for the whole wave
+                    hit = collide_pairs<1>([&q, e](int, auto, float (&r1)[8], float (&r2)[8]) {
+                        float w[10];
+#pragma unroll
+                        for (int k = 0; k < 10; k++) w[k] = launder(q[k][e], Laundered{});
+                        pose_pair_rects(w, r1, r2);
+                    });
+                }
+                bits |= hit << e;
+            }
+            const uint32_t packed = bits_to_bytes4(bits);
             my_count += (uint32_t)__popc(packed);
             __builtin_nontemporal_store(packed, reinterpret_cast<uint32_t*>(out) + g);
         } else {

@@ -84,6 +84,33 @@ def random_tables(num_poses: int, num_variances: int, seed: int = 7, shape_varia
     return poses.view(POSE_DT).reshape(-1), sd.view(STD_DT).reshape(-1), var
 
 
+def touching_pose_pairs(n: int, seed: int, scale: float = 1.0, offset: float = 0.0) -> np.ndarray:
+    """float32 [10][n] pose pairs (cx, cy, w, h, theta twice) built to TOUCH: the second rectangle's centre sits along one of the
+    four frame directions of the pair at the distance where that direction's gap is zero, moved by 0 or a few parts in
+    1e-7 .. 1e-3 either way, and anywhere along the direction's normal.  A third of the pairs have parallel or perpendicular
+    frames.  The workload for the closed-form pair test (c2d_sat.hip pose_pair_closed_form, c2d_mc.hip model_gap): most of
+    these pairs are decided inside or right at its margin."""
+    rng = np.random.Generator(np.random.Philox(seed))
+    F = np.float32
+    w1, h1, w2, h2 = [(rng.uniform(0.2, 4, n) * scale).astype(F) for _ in range(4)]
+    t1 = rng.uniform(-3.2, 3.2, n).astype(F)
+    t2 = np.where(rng.random(n) < 0.3, t1 + rng.choice([0.0, np.pi / 2, np.pi], n), rng.uniform(-3.2, 3.2, n)).astype(F)
+    x1, y1 = [((rng.uniform(-1, 1, n) + offset) * scale).astype(F) for _ in range(2)]
+    s1, c1, s2, c2 = np.sin(t1.astype(np.float64)), np.cos(t1.astype(np.float64)), np.sin(t2.astype(np.float64)), np.cos(t2.astype(np.float64))
+    which = rng.integers(0, 4, n)
+    ex = np.choose(which, [c1, -s1, c2, -s2])
+    ey = np.choose(which, [s1, c1, s2, c2])
+    hw, hh, hx, hy = [np.abs(v.astype(np.float64)) / 2 for v in (w1, h1, w2, h2)]
+    ext = hw * np.abs(ex * c1 + ey * s1) + hh * np.abs(-ex * s1 + ey * c1) + hx * np.abs(ex * c2 + ey * s2) + hy * np.abs(-ex * s2 + ey * c2)
+    rel = rng.choice([0.0, 1e-7, -1e-7, 3e-7, -3e-7, 1e-6, -1e-6, 1e-5, -1e-5, 1e-4, -1e-4, 1e-3, -1e-3], n)
+    dist = ext * (1 + rel)
+    sign = rng.choice([-1.0, 1.0], n)
+    lateral = rng.uniform(-0.3, 0.3, n) * scale
+    x2 = (x1 + sign * dist * ex - lateral * ey).astype(F)
+    y2 = (y1 + sign * dist * ey + lateral * ex).astype(F)
+    return np.stack([x1, y1, w1, h1, t1, x2, y2, w2, h2, t2]).astype(F)
+
+
 def inject_non_finite(values: np.ndarray, seed: int, frac: float = 0.5, axis_items: int = -1) -> np.ndarray:
     """Copy of `values` (float32 [planes][n], item index last) in which about `frac` of the items get one to three of
     their coordinates replaced by NaN, +inf, -inf or +-3e38 (large enough for products to overflow).  Used by the tests

@@ -351,3 +351,24 @@ def test_mc_parallel_axis_certificates_on_razor_thin_overlaps(eng, oracle, pos, 
             eng.mc_pair(W, H, robot_theta_pos, pose, sd, 21, 3, begin, n, d)
             assert int(d.get()[0]) == oracle.mc_pair(W, H, robot_theta_pos, pose, sd, 21, 3, begin, n), (robot_theta_pos, begin)
             d.free()
+
+
+@pytest.mark.parametrize("scale,offset", [(1.0, 0.0), (1.0, 40.0), (1e-3, 0.0), (1e3, 0.0)])
+def test_mc_closed_form_on_touching_scenes(eng, oracle, wl, scale, offset):
+    """The full evaluation decides a sample by the sign of the closed-form gap when it exceeds a proven margin and by the
+    reference's vertex arithmetic otherwise (c2d_mc.hip model_gap).  Scenes whose robot and obstacle TOUCH along one of the four
+    frame directions (workloads.touching_pose_pairs, moved into the obstacle's frame), drawn with standard deviations of
+    1e-7 .. 1e-4 of the scene's size, keep nearly every sample at the margin: the hit counts must stay the oracle's."""
+    pairs = wl.touching_pose_pairs(48, seed=int(offset) + 5, scale=scale, offset=offset).astype(np.float64)
+    rng = np.random.default_rng(3)
+    for i in range(pairs.shape[1]):
+        x1, y1, w1, h1, t1, x2, y2, w2, h2, t2 = pairs[:, i]
+        c, s = np.cos(-t2), np.sin(-t2)
+        pos = (float(c * (x1 - x2) - s * (y1 - y2)), float(s * (x1 - x2) + c * (y1 - y2)))
+        sg = float(rng.choice([1e-7, 1e-6, 1e-5, 1e-4])) * scale
+        sd = (sg, sg * float(rng.choice([0.0, 1.0])), float(rng.choice([0.0, 1e-7, 1e-5])), sg * float(rng.choice([0.0, 0.0, 1.0])), 0.0)
+        pose = (float(w2), float(h2), float(t1 - t2))
+        d = eng.zeros(1, np.uint64)
+        eng.mc_pair(float(w1), float(h1), pos, pose, sd, 31, i, 0, 20_000, d)
+        assert int(d.get()[0]) == oracle.mc_pair(float(w1), float(h1), pos, pose, sd, 31, i, 0, 20_000), (i, pos, pose, sd)
+        d.free()

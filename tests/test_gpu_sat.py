@@ -475,3 +475,25 @@ def test_non_finite_polygons(eng, oracle, wl, rows, kmin, kmax, n):
     assert np.array_equal(d_out.get(), ref) and int(d_cnt.get()[0]) == ref_cnt
     for a in (dvx, dvy, dk, d_out, d_cnt):
         a.free()
+
+
+@pytest.mark.parametrize("scale,offset", [(1.0, 0.0), (1.0, 60.0), (1e-4, 0.0), (1e3, 0.0), (1e-13, 0.0), (1e14, 0.0)])
+def test_pose_closed_form_on_touching_pairs(eng, oracle, wl, scale, offset):
+    """The pose-format kernel decides a pair by the closed-form gap when it exceeds a proven margin and by the vertex arithmetic
+    otherwise (c2d_sat.hip pose_pair_closed_form).  Pairs built to touch along a frame direction, a few parts in 1e-7 .. 1e-3
+    either side (workloads.touching_pose_pairs), at several scales — down to extents below the 1e-12 floor and up to the 1e15
+    ceiling of the closed form — and far from the origin: every boolean is the oracle's."""
+    n = 200_003
+    poses = wl.touching_pose_pairs(n, seed=int(offset) + 9, scale=scale, offset=offset)
+    ref, ref_cnt = oracle.sat_rect_pairs_pose(poses)
+    assert 0.2 < ref.mean() < 0.8
+    for off in (0, 1):  # 16-byte aligned planes (4 pairs per lane) and unaligned ones (the plain kernel)
+        host = np.zeros((10, n + 4), np.float32)
+        host[:, off:off + n] = poses
+        d_pose = eng.to_device(host)
+        rows = [d_pose.row(k) + 4 * off for k in range(10)]
+        d_out, d_cnt = eng.zeros(n, np.uint8), eng.zeros(1, np.uint64)
+        eng.sat_rect_pairs_pose(rows, n, d_out, d_cnt)
+        assert np.array_equal(d_out.get(), ref) and int(d_cnt.get()[0]) == ref_cnt
+        for a in (d_pose, d_out, d_cnt):
+            a.free()

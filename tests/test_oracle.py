@@ -458,29 +458,8 @@ def test_closed_form_gap_decides_like_the_oracle_on_random_pairs(oracle):
         assert thin < (0.2 if pos >= 100 or lo < 0.01 else 0.02), (pos, lo, hi, scale, thin)
 
 
-def test_closed_form_gap_on_razor_thin_pairs(oracle):
-    """Pairs built to touch: the second rectangle's centre sits along an axis of either frame at exactly the distance where that
-    axis' gap is zero, moved by a few parts in 1e-7 .. 1e-3.  Every decision the closed form takes must be the oracle's."""
-    rng = np.random.default_rng(12)
-    n = 40_000
-    F = np.float32
-    for scale, off in ((1.0, 0.0), (1.0, 50.0), (1e-4, 0.0), (1e3, 0.0)):
-        w1, h1, w2, h2 = [(rng.uniform(0.2, 4, n) * scale).astype(F) for _ in range(4)]
-        t1 = rng.uniform(-3.2, 3.2, n).astype(F)
-        t2 = np.where(rng.random(n) < 0.3, t1 + rng.choice([0.0, np.pi / 2, np.pi], n), rng.uniform(-3.2, 3.2, n)).astype(F)
-        x1, y1 = [(rng.uniform(-1, 1, n) * scale + off * scale).astype(F) for _ in range(2)]
-        s1, c1 = [v.astype(np.float64) for v in oracle.sincosf(t1)]
-        s2, c2 = [v.astype(np.float64) for v in oracle.sincosf(t2)]
-        which = rng.integers(0, 4, n)
-        ex = np.choose(which, [c1, -s1, c2, -s2])
-        ey = np.choose(which, [s1, c1, s2, c2])
-        hw, hh, hx, hy = [np.abs(v.astype(np.float64)) / 2 for v in (w1, h1, w2, h2)]
-        ext = (hw * np.abs(ex * c1 + ey * s1) + hh * np.abs(-ex * s1 + ey * c1) + hx * np.abs(ex * c2 + ey * s2) + hy * np.abs(-ex * s2 + ey * c2))
-        rel = rng.choice([0.0, 1e-7, -1e-7, 3e-7, -3e-7, 1e-6, -1e-6, 1e-5, -1e-5, 1e-4, -1e-4, 1e-3, -1e-3], n)
-        dist = ext * (1 + rel) / (ex * ex + ey * ey)
-        sign = rng.choice([-1.0, 1.0], n)
-        lateral = rng.uniform(-0.3, 0.3, n) * scale   # along the axis' normal: does not change this axis' gap
-        x2 = (x1 + sign * dist * ex - lateral * ey).astype(F)
-        y2 = (y1 + sign * dist * ey + lateral * ex).astype(F)
-        thin = _closed_form_against_oracle(oracle, (x1, y1, w1, h1, t1, x2, y2, w2, h2, t2))
+def test_closed_form_gap_on_razor_thin_pairs(oracle, wl):
+    """Pairs built to touch (workloads.touching_pose_pairs): every decision the closed form takes must be the oracle's."""
+    for seed, (scale, off) in enumerate(((1.0, 0.0), (1.0, 50.0), (1e-4, 0.0), (1e3, 0.0))):
+        thin = _closed_form_against_oracle(oracle, wl.touching_pose_pairs(40_000, seed=12 + seed, scale=scale, offset=off))
         assert thin > 0.01, "the construction is meant to land inside the margin often"
