@@ -404,17 +404,17 @@ def main() -> None:
                     "roofline": {"bound": "hbm", "kernel": "sat_rect_pose_kernel<4, 64>", "achieved": round(pose_gbs, 1), "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": round(pose_gbs / HBM_PEAK_GBS, 4), "traffic": None,
                                  "step_ms_distribution": step_distribution(pose_step, min(args.steps, 100))},
-                    "note": "rectangles rebuilt from (cx,cy,w,h,theta) per pair (2 sincos + 2 rectangle builds + the certified SAT): the format "
-                            "with the most arithmetic per byte"}
+                    "note": "a pair is decided from (cx,cy,w,h,theta) by the closed-form gap of the two rectangles when it exceeds a proven "
+                            "rounding margin (2 sincos + ~70 instructions), by the reference's vertex arithmetic otherwise (about one pair in "
+                            "1e4 here): HBM-bound since round 3"}
         c = counts.get("sat_rect_pose.config2")
         if c and n == c.get("pairs"):
             lane = n / (pms * 1e-3) * c["valu_instr_per_pair"] / 1e12
             pose_leg["valu_roofline"] = {"bound": "valu", "achieved": round(lane, 2), "peak": VALU_PEAK_TLANE, "unit": "T VALU lane-instr/s",
                                          "frac": round(lane / VALU_PEAK_TLANE, 4), "valu_instr_per_pair": c["valu_instr_per_pair"],
                                          "instr_source": c.get("source"),
-                                         "note": "peak priced at the nominal 2.4 GHz; under a VALU-heavy streaming kernel the chip holds a lower clock "
-                                                 "(round 2 measured ~1.4 ticks/ns under this kernel: profiles/r02a_pose_probe.txt), so a VALU fraction "
-                                                 "near 0.6 of the nominal peak is the VALU roof in practice"}
+                                         "note": "peak priced at the nominal 2.4 GHz; secondary to the HBM roofline above since the closed-form "
+                                                 "pair test (round 3) took the kernel from 294 to the recorded instruction count per pair"}
             pose_leg["roofline"]["traffic"] = c.get("hbm_bytes_per_launch")
             pose_leg["roofline"]["traffic_source"] = "recorded, not measured in this run: %s" % c.get("source")
     del pose

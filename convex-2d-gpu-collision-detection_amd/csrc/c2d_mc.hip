@@ -20,18 +20,20 @@
 // proves a miss (bounding-disk argument, make_scene) is dropped after its first
 // Box-Muller pair, or — from the raw radius word, four samples per Philox block — before any transcendental; the
 // undecided samples of a wave are compacted through an LDS queue so that the full
-// evaluation always runs on 64 busy lanes.
+// evaluation always runs on 64 busy lanes; and the full evaluation itself decides a sample from the closed-form gap of
+// the two rectangles (model_gap) whenever that gap exceeds a proven rounding margin, with the reference's vertex arithmetic
+// (convex_collide's projections and comparisons, float for float) behind it for the thin ones.
 #include "c2d_internal.hpp"
 #include "c2d_math.hpp"
 
 namespace c2d {
 
 // ---- census build (-DC2D_MC_STATS, `make lib-mcstats`; never the product): where the samples of a workload go.  Wave-uniform
-// counts are added to eight device words — [0] samples handed to a wave, [1] of those on the FAR path, [2] on the NEAR path,
+// counts are added to device words — [0] samples handed to a wave, [1] of those on the FAR path, [2] on the NEAR path,
 // [3] candidates left by the radius-word test (far path), [4] first Box-Muller pairs evaluated (centre of the obstacle),
-// [5] samples that reach the full evaluation, [6] full-evaluation passes (64 lanes each) in which a second axis of a
-// parallel pair had to be evaluated after all, [7] hits, [8] evaluated samples that the robot's axes do not separate, [9] of
-// those the ones queued for a later pass over the obstacle's axes — and read by c2d_debug_mc_stats (tests/tools/mc_stats.py).
+// [5] samples that reach the full evaluation, [6] second axes of a parallel pair evaluated by the vertex arithmetic, [7] hits,
+// [8] evaluation passes (64 lanes each) that the closed-form test left undecided for some lane, so that the wave ran the vertex
+// arithmetic — and read by c2d_debug_mc_stats (tests/tools/mc_stats.py).
 #ifdef C2D_MC_STATS
 __device__ unsigned long long c2d_mc_stats_words[12];
 #define C2D_MC_STAT(i, v)                                                                                     \

@@ -164,8 +164,10 @@ int c2d_sat_rect_pairs_aos(c2d_ctx* ctx, const float* d_r1, const float* d_r2, s
                            uint8_t* d_out, unsigned long long* d_count, c2d_stream stream);
 
 /* c2d_sat_rect_pairs_pose: the same test on pose-format input: for each pair,
- * both rectangles are built on the fly exactly as c2d_rects_from_poses would
- * (utils.cu:119-142) and then tested (utils.cu:159-184).
+ * the result is that of building both rectangles exactly as c2d_rects_from_poses would
+ * (utils.cu:119-142) and testing them (utils.cu:159-184) — for every bit pattern.  The kernel
+ * reaches it from the closed-form gap of the two rectangles wherever that gap exceeds a proven
+ * rounding margin, and by that very vertex arithmetic elsewhere.
  *   d_pose_planes[0..4] : rectangle 1: cx, cy, w, h, theta   (f32[n] each)
  *   d_pose_planes[5..9] : rectangle 2: cx, cy, w, h, theta */
 int c2d_sat_rect_pairs_pose(c2d_ctx* ctx, const float* const d_pose_planes[10], size_t n,

@@ -27,6 +27,15 @@ def one(eng, rng, idx):
     ns = int(rng.choice([1, 2, 63, 65, int(rng.integers(1, 400)), int(rng.integers(400, 2500))]))
     rw, rh = float(rng.uniform(0.5, 5)), float(rng.uniform(0.5, 3))
     spread = float(rng.choice([0.5, 2.0, 4.0, 8.0]))
+    if rng.random() < 0.3:  # the whole scene at another scale, or the obstacles as slivers: the closed-form evaluation's margins scale with both
+        k = np.float32(10.0 ** int(rng.integers(-9, 10)))
+        tp, ts = tp.copy(), ts.copy()
+        sliver = np.float32(1e-4) if rng.random() < 0.3 else np.float32(1.0)
+        tp["width"] *= k
+        tp["height"] *= k * sliver
+        for f in ("x", "y", "width", "height"):
+            ts[f] *= k
+        rw, rh, spread = float(np.float32(rw) * k), float(np.float32(rh) * k), float(np.float32(spread) * k)
     seed, base = int(rng.integers(1 << 40)), int(rng.integers(1 << 33))
     schedule = [(0, 0, 0), (10000, 10000, 0), (64, 1000, 640), (100, 7777, 1000), (1000, 33333, 5000), (1500, 100000, 3000)][int(rng.integers(6))]
     max_samples = int(rng.choice([1000, 3000, 20000, 50000, 150000]))

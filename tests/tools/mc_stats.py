@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool: where the Monte-Carlo samples of the bench workloads go, counted by the census build of the kernels
 (`make lib-mcstats`, -DC2D_MC_STATS): far / near path, candidates left by the radius-word test, centres evaluated, samples
-that reach the full evaluation, passes in which a parallel axis had to be evaluated after all, hits.  With `--record` the
+that reach the full evaluation, evaluation passes that the closed-form test could not decide, hits.  With `--record` the
 evaluated-sample fraction of the config-4 shard is written into profiles/measured_counts.json (bench.py quotes it beside the
 drawn-sample rate).  usage: mc_stats.py [--record]"""
 import ctypes as C
@@ -21,7 +21,7 @@ import importlib  # noqa: E402
 wl = importlib.import_module("c2d_amd.workloads")
 LIB = os.path.join(ROOT, "convex-2d-gpu-collision-detection_amd", "lib", "libc2d_mcstats.so")
 NAMES = ["samples", "far_path", "near_path", "radius_candidates", "centres_evaluated", "fully_evaluated", "parallel_axis_fallbacks", "hits",
-         "robot_axes_survivors", "survivors_queued", "unused10", "unused11"]
+         "vertex_arithmetic_passes", "unused9", "unused10", "unused11"]
 
 
 def stats(eng, reset=True):
@@ -37,10 +37,9 @@ def show(title, st):
     n = st["samples"]
     print(f"{title}: {n:.4g} samples; far path {st['far_path'] / n:.3f}, near path {st['near_path'] / n:.3f}; radius candidates (far) "
           f"{st['radius_candidates'] / max(st['far_path'], 1):.5f} of the far samples; centres evaluated {st['centres_evaluated'] / n:.4f}; "
-          f"fully evaluated {st['fully_evaluated'] / n:.5f}; hits {st['hits'] / n:.5f}; full-evaluation passes with a parallel-axis "
-          f"fallback {st['parallel_axis_fallbacks']} of about {st['fully_evaluated'] / 64:.4g}; "
-          f"survive the robot's axes {st['robot_axes_survivors'] / max(st['fully_evaluated'], 1):.4f} of the evaluated (queued for a later "
-          f"obstacle-axes pass: {st['survivors_queued'] / max(st['robot_axes_survivors'], 1):.3f} of them)")
+          f"fully evaluated {st['fully_evaluated'] / n:.5f}; hits {st['hits'] / n:.5f}; evaluation passes (64 lanes) in which a thin closed-form "
+          f"result sent the wave through the vertex arithmetic: {st['vertex_arithmetic_passes']} of about {st['fully_evaluated'] / 64:.4g} "
+          f"(and {st['parallel_axis_fallbacks']} second axes of a parallel pair evaluated in those)")
 
 
 def scenes(eng, ns, max_samples):
