@@ -27,6 +27,10 @@ python3 convex-2d-gpu-collision-detection_amd/csrc/tools/scenes_trace.py digest 
 cp $O/bench.json profiles/${TAG}_bench.json
 cp $O/bench_under_rocprof.json profiles/${TAG}_bench_under_rocprof.json
 python3 profiles/counts.py write $TAG   # measured_counts.json is generated from this tag's digests (tests/test_profiles.py verifies it)
+# the bench line quotes measured_counts.json (instruction counts, PMC traffic): run it again now that the file is this tag's own,
+# so that the committed line never carries the previous collection's counts for a kernel that has changed since
+echo "== un-profiled bench again, with this tag's counts"; (cd /tmp && timeout -k 10 500 python3 $R/bench.py > $O/bench.json 2> $O/bench.err)
+cp $O/bench.json profiles/${TAG}_bench.json
 mkdir -p $R/gpurun_out/${TAG}_profiles && cp profiles/${TAG}_* $R/gpurun_out/${TAG}_profiles/
 # the raw traces are large: keep only what the digests came from, compressed
 find $O -name "*.csv" -size +2M -exec gzip -f {} \;

@@ -37,14 +37,21 @@ with max_samples 120 000, default batch = 1e5 data points with max_samples 4 020
 
 ## 1. Shipped build
 
-Adaptive kernels: evaluation-only scene fields parked in LDS, two-stage full evaluation with a survivor queue.  mc_pair_kernel:
-scene in registers, obstacle axes always in place.
+Every kernel: closed-form full evaluation (model_gap), the fields of the vertex arithmetic behind it (robot vertices, parallel-axis
+certificates) parked in LDS.  Adaptive kernels: the other evaluation-only scene fields parked too, 7 waves per SIMD (72 VGPRs).
+mc_pair_kernel: those fields in registers (77 VGPRs).
 
 ```""")
 print(digest([]))
 print("""```
 
 No scratch access executes inside a sample loop: every one is at depth 0 (prologue) or depth 1 (once per work item).
+
+## 1b. The same at 6 waves per SIMD (80 VGPRs): `-DC2D_MC_ADV_WAVES=6`
+
+```""")
+print(digest(["-DC2D_MC_ADV_WAVES=6"]))
+print("""```
 
 ## 2. The scene in registers everywhere: `-DC2D_MC_PARK_ADAPTIVE=0`
 
@@ -73,9 +80,13 @@ print("""```
 | parked in the adaptive kernels, registers in mc_pair_kernel | 0.547-0.548 | 383-385 | 39.2-39.5 |
 | + two-stage full evaluation in the adaptive kernels (`-DC2D_MC_IN_PLACE_FROM=0` switches it off): **shipped** | **0.547** | **378.5-379.0** | **38.9-39.1** |
 | ... queueing from 32 / 48 survivors, or always | 0.556 / 0.557 / 0.594 (when also applied to mc_pair_kernel) | 377.0 / 377.9 / 379.8 | 38.8 / 38.8 / 39.1 |
+| closed-form full evaluation (`model_gap`; vertex arithmetic only behind a thin result, no survivor queue), 6 waves (another box: the row above reads 0.549 / 383.5 / 39.2 there) | **0.411** | 335-337 | 33.1-33.3 |
+| ... adaptive kernels at 5 / 7 waves per SIMD: **7 shipped** | 0.412 | 349 / **324-325** | 34.7 / **32.5** |
 
 Reading: the spills of round 2 (and the larger ones the certificates added) were HARMLESS - removing every scratch access from the
 sample loops changes the config-4 shard by less than 0.5 % - and the obvious cure, scalar registers, is a loss on this kernel because
 its scalar file is already full of lane masks.  What did help is arithmetic: a full evaluation is 74 VALU instructions shorter with
-the certificates, and on the dataset workloads the obstacle's axes now run only for the samples the robot's axes leave over.
+the certificates, and with the closed-form test it no longer builds vertices or projects anything for all but one pass in a hundred
+(28 instructions for the four frame directions instead of ~150 for the vertex arithmetic), which also shortened the live ranges enough
+for a seventh wave per SIMD.
 """)
