@@ -463,3 +463,62 @@ def test_closed_form_gap_on_razor_thin_pairs(oracle, wl):
     for seed, (scale, off) in enumerate(((1.0, 0.0), (1.0, 50.0), (1e-4, 0.0), (1e3, 0.0))):
         thin = _closed_form_against_oracle(oracle, wl.touching_pose_pairs(40_000, seed=12 + seed, scale=scale, offset=off))
         assert thin > 0.01, "the construction is meant to land inside the margin often"
+
+
+def test_closed_form_error_budget(oracle, wl):
+    """The inequality the closed-form margin rests on (c2d_mc.hip model_gap): on every one of the reference's eight axes the smaller
+    of the two computed overlaps of utils.cu:178 differs from -G(n) = -2 h G_e of the real model rectangles by at most 2E,
+    E = 5.1u |a^|_1 C + 16.1u C^2.  Measured in float64 on random and on touching pairs; the worst ratio seen is about 0.15."""
+    F, D, u = np.float32, np.float64, 2.0 ** -24
+    rng = np.random.default_rng(5)
+    worst = 0.0
+    cases = []
+    for pos, lo, hi, scale in ((8, 0.1, 5, 1), (8, 0.1, 5, 1e-3), (100, 0.1, 5, 1), (1000, 0.01, 1, 1), (3, 3, 6, 1e4)):
+        n = 40_000
+        xy = [rng.uniform(-pos, pos, n) * scale for _ in range(4)]
+        wh = [rng.uniform(lo, hi, n) * scale for _ in range(4)]
+        th = [rng.uniform(-7, 7, n) for _ in range(2)]
+        cases.append(np.stack([xy[0], xy[1], wh[0], wh[1], th[0], xy[2], xy[3], wh[2], wh[3], th[1]]).astype(F))
+    cases.append(wl.touching_pose_pairs(40_000, seed=3))
+    cases.append(wl.touching_pose_pairs(40_000, seed=4, offset=30.0))
+    for p in cases:
+        x1, y1, w1, h1, t1, x2, y2, w2, h2, t2 = p
+        r1, r2 = oracle.rects_from_poses(x1, y1, w1, h1, t1), oracle.rects_from_poses(x2, y2, w2, h2, t2)
+        (s1, c1), (s2, c2) = oracle.sincosf(t1), oracle.sincosf(t2)
+        hx1, hy1, hx2, hy2 = [np.abs(v.astype(D)) / 2 for v in (w1, h1, w2, h2)]
+        C = np.maximum(np.maximum(np.abs(x1), np.abs(y1)).astype(D) + hx1 + hy1, np.maximum(np.abs(x2), np.abs(y2)).astype(D) + hx2 + hy2)
+        for r, c, s, hx, hy in ((r1, c1, s1, hx1, hy1), (r2, c2, s2, hx2, hy2)):
+            for i in range(4):
+                ax, ay = (r[(2 * i + 2) & 7] - r[2 * i]).astype(F), (r[(2 * i + 3) & 7] - r[2 * i + 1]).astype(F)
+
+                def interval(rr):
+                    q = np.stack([((ax * rr[2 * k]).astype(F) + (ay * rr[2 * k + 1]).astype(F)).astype(F) for k in range(4)])
+                    return q.min(0).astype(D), q.max(0).astype(D)
+
+                (mn1, mx1), (mn2, mx2) = interval(r1), interval(r2)
+                overlap = np.minimum(mx1 - mn2, mx2 - mn1)
+                ex, ey, h = (c.astype(D), s.astype(D), hx) if i % 2 == 0 else (-s.astype(D), c.astype(D), hy)
+
+                def extent(cc, ss, a, b):
+                    cc, ss = cc.astype(D), ss.astype(D)
+                    return a * np.abs(ex * cc + ey * ss) + b * np.abs(-ex * ss + ey * cc)
+
+                gap = np.abs(ex * (x2.astype(D) - x1) + ey * (y2.astype(D) - y1)) - extent(c1, s1, hx1, hy1) - extent(c2, s2, hx2, hy2)
+                E = 5.1 * u * (np.abs(ax.astype(D)) + np.abs(ay.astype(D))) * C + 16.1 * u * C * C
+                ratio = np.abs(overlap + 2 * h * gap) / (2 * E)
+                assert (ratio <= 1.0).all(), (i, float(ratio.max()))
+                worst = max(worst, float(ratio.max()))
+    assert 0.01 < worst < 0.5, worst
+
+
+def test_sincos_is_a_rotation_to_within_2_pow_minus_20(oracle):
+    """model_gap's budget writes a rectangle's extent along its own edge as h, not h (c^2 + s^2), and allows 16uC for it:
+    sincos_ returns |c^2 + s^2 - 1| <= 2^-20 and |c|, |s| <= 1 for every finite angle tried (dense near the octant seams too)."""
+    rng = np.random.default_rng(9)
+    k = rng.integers(-40, 41, 60_000)
+    seams = (k * (np.pi / 4) + rng.normal(0, 1e-6, k.size)).astype(np.float32)
+    x = np.concatenate([rng.uniform(-7, 7, 120_000), rng.uniform(-1e5, 1e5, 30_000), rng.normal(0, 1e-3, 30_000), seams]).astype(np.float32)
+    s, c = oracle.sincosf(x)
+    s, c = s.astype(np.float64), c.astype(np.float64)
+    assert np.abs(c * c + s * s - 1).max() <= 2.0 ** -20
+    assert np.abs(c).max() <= 1.0 and np.abs(s).max() <= 1.0
