@@ -519,10 +519,36 @@ def main() -> None:
             if c.get("evaluated_fraction"):
                 scenes_leg["evaluated_samples_per_s"] = float(hsum[1].item()) / sel * c["evaluated_fraction"]
                 scenes_leg["evaluated_fraction"] = c["evaluated_fraction"]
-                scenes_leg["evaluated_note"] = "samples that reach the full evaluation (second Box-Muller pair, vertices, SAT); recorded: %s" % c.get("evaluated_source")
+                scenes_leg["evaluated_note"] = ("samples that reach the full evaluation (second Box-Muller pair, rotation, closed-form test; vertices and the "
+                                               "SAT's own arithmetic for a thin result); recorded: %s" % c.get("evaluated_source"))
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             scenes_keep = {"tables": (tp, ts), "scenes": d_sc.get(), "hits": t_h.cpu().numpy().view(np.uint32), "used": t_u.cpu().numpy().view(np.uint32),
                            "base": base}
+        # fixed-samples mode: max_samples = 1000, i.e. exactly one 1000-sample step per data point, no adaptivity —
+        # the per-data-point floor of the loop (scene set-up, one wave per data point, one decide step)
+        fixed_n = 1000
+        with torch.cuda.stream(stream):
+            t_h.zero_()
+            t_u.zero_()
+        torch.cuda.synchronize()
+        barrier()
+        f0 = time.perf_counter()
+        eng.mc_scenes_async(d_p, 65536, d_s, 65536, d_sc, ns, 4.07, 1.74, wl.DEFAULT_BINS, wl.DEFAULT_BIN_ACCURACY,
+                            fixed_n, 11, base, t_h.data_ptr(), t_u.data_ptr(), None, stream=sh)
+        with torch.cuda.stream(stream):
+            fsum = torch.stack([t_h.sum(dtype=torch.int64), t_u.sum(dtype=torch.int64)])
+        all_reduce_sum(fsum)
+        torch.cuda.synchronize()
+        barrier()
+        fel = shd.max_over_ranks(time.perf_counter() - f0, dev)
+        if int(t_u.min().item()) != fixed_n or int(t_u.max().item()) != fixed_n:
+            raise SystemExit("bench: fixed-samples mode drew other than %d samples for some data point" % fixed_n)
+        scenes_leg["fixed_samples"] = {"samples_per_point": fixed_n, "seconds": round(fel, 5), "data_points_per_s": ns * world / fel,
+                                       "samples_per_s": float(fsum[1].item()) / fel, "pooled_hit_fraction": float(fsum[0].item()) / float(fsum[1].item()),
+                                       "note": "every data point sampled exactly 1000 times (max_samples = 1000: one schedule step, no stop rule at work)"}
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            scenes_fixed_hits = t_h[:2000].cpu().numpy().view(np.uint32)
+            scenes_keep["fixed_hits"] = scenes_fixed_hits
         for a_ in (d_p, d_s, d_sc):
             a_.free()
         del t_h, t_u
@@ -748,6 +774,14 @@ def main() -> None:
             scenes_leg["cpu_baseline"] = {"value": done / cel, "unit": "data_points/s", "samples_per_s": cpu_samples / cel, "cores": oracle.num_threads(),
                                           "kind": "port", "sample": f"first {done} data points of the shard ({cpu_samples} samples, {cel:.1f} s), OpenMP over scenes",
                                           "parity": scenes_leg["parity"]}
+            if "fixed_hits" in scenes_keep:  # the fixed-samples sub-leg: its first 2000 data points against the oracle
+                fh = scenes_keep["fixed_hits"]
+                rh, ru, _, _ = oracle.mc_scenes(tp, ts, scenes_keep["scenes"][:len(fh)], 4.07, 1.74, wl.DEFAULT_BINS, wl.DEFAULT_BIN_ACCURACY,
+                                                1000, 11, scenes_keep["base"])
+                fbad = int((rh != fh).sum()) + int((ru != 1000).sum())
+                scenes_leg["fixed_samples"]["parity"] = f"hits equal on {len(fh) - fbad} of {len(fh)} data points checked"
+                if fbad:
+                    raise SystemExit("PARITY FAILURE: fixed-samples Monte-Carlo hits differ from the CPU oracle")
             scenes_keep = None
 
     if rank == 0:
