@@ -372,3 +372,18 @@ def test_mc_closed_form_on_touching_scenes(eng, oracle, wl, scale, offset):
         eng.mc_pair(float(w1), float(h1), pos, pose, sd, 31, i, 0, 20_000, d)
         assert int(d.get()[0]) == oracle.mc_pair(float(w1), float(h1), pos, pose, sd, 31, i, 0, 20_000), (i, pos, pose, sd)
         d.free()
+
+
+def test_canonical_math_over_whole_domains(eng, oracle):
+    """Device == oracle, bit for bit, on EVERY input the Box-Muller transform can see: all 2^32 angle words, every float in
+    [2^-33, 1] for the logarithm and in [2^-24, 64] for the square root (tests/tools/math_exhaustive.py holds the full set,
+    float angles and the transform itself included: profiles/r03_math_exhaustive.txt)."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("math_exhaustive", os.path.join(os.path.dirname(__file__), "tools", "math_exhaustive.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    assert tool.sweep(eng, eng.MATH_SINCOS_U32, "sin/cos of 2 pi y / 2^32, every 32-bit word y", [(0, 0xFFFFFFFF)]) == 0
+    assert tool.sweep(eng, eng.MATH_LOG, "log(u), every float in [2^-33, 1]", [(tool.fbits(2.0 ** -33), tool.fbits(1.0))]) == 0
+    assert tool.sweep(eng, eng.MATH_SQRT, "sqrt(v), every float in [2^-24, 64]", [(tool.fbits(2.0 ** -24), tool.fbits(64.0))]) == 0
