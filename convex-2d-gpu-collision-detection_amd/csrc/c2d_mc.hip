@@ -1412,9 +1412,17 @@ int c2d_mc_scenes(c2d_ctx* ctx, const c2d_mc_scenes_args* a, c2d_stream stream)
     // Work items of a step = active scenes x chunks per scene.  The chip holds 5 waves per SIMD of this kernel (5120);
     // items cost between ~100 and ~430 instructions per sample depending on the scene, so the step only balances when
     // there are many more items than resident waves: CUs x 512 items of at least 1024 samples.  Reference-default batch
-    // (1e5 scenes, 58 steps): 74.9 ms with CUs x 32 items, 67.8 / 63.6 / 61.2 ms with x 64 / x 128 / x 512.
-    S.want_waves = cus * 512;
-    S.min_chunk = 1024;
+    // (1e5 scenes, 58 steps): 74.9 ms with CUs x 32 items, 67.8 / 63.6 / 61.2 ms with x 64 / x 128 / x 512.  Measured again at the
+    // round-3 kernels: x 128 / x 256 / x 512 = 33.7 / 32.6 / 32.5 ms, and 2048 / 4096 samples at least = 32.6 / 32.4 ms (the scene
+    // set-up per work item does not show); the config-4 shard does not move (324-327 ms) for any of them.
+#ifndef C2D_MC_ITEMS_PER_CU
+#define C2D_MC_ITEMS_PER_CU 512
+#endif
+#ifndef C2D_MC_MIN_CHUNK
+#define C2D_MC_MIN_CHUNK 1024
+#endif
+    S.want_waves = cus * C2D_MC_ITEMS_PER_CU;
+    S.min_chunk = C2D_MC_MIN_CHUNK;
     // number of schedule steps until n_samples >= max_samples (ccp.cu:281-287)
     uint32_t steps = 0;
     for (uint64_t ns = 0; ns < a->max_samples; steps++) ns += ns < S.switch_at ? S.small_batch : S.large_batch;
