@@ -410,9 +410,6 @@ C2D_DEV unsigned long long sample_collides_mask(const Scene& sc, const float (&o
 #endif
 }
 
-#ifndef C2D_MC_PRETEST_HOLDOFF
-#define C2D_MC_PRETEST_HOLDOFF 3
-#endif
 #ifndef C2D_MC_ILP
 #define C2D_MC_ILP 1  // 1, 2, 3 blocks side by side: 425 / 422 / 453 ms on the config-4 shard; 1 keeps the LDS at 4.5 KB per wave
 #endif
@@ -423,14 +420,17 @@ C2D_DEV unsigned long long sample_collides_mask(const Scene& sc, const float (&o
 [[maybe_unused]] constexpr int kIlp = C2D_MC_ILP;  // radius blocks computed side by side on the far-scene path
 constexpr int kQueueSlots = 128;      // < 64 left over + at most 64 pushed per step
 constexpr int kCandSlots = 64 + 256 * C2D_MC_ILP;  // < 64 left over + every sample of the iterations fetched together
+constexpr int kNearSlots = 64 + 256;  // < 64 left over + the four members of 64 groups
 
 // Per-wave LDS.  Two ways to run a scene, chosen per scene (wave-uniform):
-//  * NEAR (the radius word proves little or nothing): a lane owns a group of four samples and shares the group's Philox
-//    blocks among them; samples the centre pretest cannot rule out are parked in `cw/idx` and evaluated 64 at a time.
+//  * NEAR (the radius word proves little or nothing): a lane owns a group of four samples and produces them back to back from
+//    the group's two Philox blocks; samples the centre pretest cannot rule out wait in `near.c/idx` and are evaluated 64 at a time.
 //  * FAR (the radius word alone proves at least every other sample to be a miss): the four radius words of a group
 //    cost one Philox block, and everything after that works on COMPACTED samples, 64 busy lanes at a time:
 //    candidates (radius word, offset) wait in `cand` for their angle word / Box-Muller / centre pretest, the undecided
-//    ones among them in `und` for the full evaluation.  Each of these later stages draws the block it needs per sample.
+//    ones among them in `und` for the full evaluation.
+// In both, an undecided sample is a centre and an offset (12 B); the block of its second Box-Muller pair is drawn by the lane that
+// evaluates it (evaluate_queued).
 struct WaveQueue {
     // Scene fields parked by lane 0 and read back as broadcast ds_read_b128 where they are used, instead of living in VGPRs
     // through every sample loop: ev[0..2] what every full evaluation reads (park_scene / load_eval; the adaptive kernels only),
@@ -438,13 +438,8 @@ struct WaveQueue {
     float4 ev[7];
     union {
         struct {
-            float4 cw[kQueueSlots];      // dx, dy, bits(radius word 2), bits(angle word 2)
-            uint32_t idx[kQueueSlots];   // sample offset within the chunk
-            // Lane-private stash of the open iteration's Philox blocks, word-major so that lane l reads word w at [w][l]
-            // without bank conflicts: the words are consumed one sub-iteration at a time, across the full evaluation of 64
-            // samples, and 16 registers of state held over that evaluation cost the kernel its sixth wave per SIMD
-            uint32_t r[4][64];           // radius block (block 0 of the groups)
-            uint32_t a[4][64];           // angle block (block 1)
+            float2 c[kNearSlots];        // dx, dy
+            uint32_t idx[kNearSlots];    // sample offset within the chunk
         } near;
         struct {
             uint2 cand[kCandSlots];      // radius word, sample offset within the chunk
@@ -606,148 +601,94 @@ C2D_DEV Scene adaptive_scene(const Scene& sc, WaveQueue& q)
     else return park_exact(sc, q);
 }
 
-// ---- NEAR: hits among samples [begin, begin + count) of one scene, computed by one wave.  A lane owns one GROUP of four
-// samples per iteration (draw layout: c2d_math.hpp), so an iteration covers 256 consecutive samples; sub-iteration
-// j = 0..3 handles member j of the 64 groups.  begin and count are arbitrary (a shard may start inside a group):
-// positions outside [begin, begin + count) are masked, never drawn into the result.
-//
-// The sub-iterations are a rolled loop, and the final flush of the queue runs through the same loop body, so that each
-// expensive piece (Box-Muller of the centre, the full evaluation) exists ONCE in the kernel's code: unrolled over j the
-// kernel was 90 KB, more than the instruction cache holds, and ran 30 % slower than the one-sample-per-lane kernel it
-// replaced.
+// ---- evaluation of queued undecided samples (centre, offset): the last `take` (<= 64) of `n` entries.  Each lane draws the
+// block of ITS sample's second Box-Muller pair (block 2 or 3 of the sample's group).  Lanes read slots that other lanes of this wave
+// wrote: LDS operations of a wave complete in order, the fences only stop the compiler from moving the reads above the writes
+// and later writes above the reads (no instruction is emitted).
+template <bool PARKED>
+C2D_DEV uint32_t evaluate_queued(const Scene& sc, WaveQueue& wq, const float2* qc, const uint32_t* qidx, uint32_t& n, uint32_t take,
+                                 uint64_t seed, uint64_t scene_id, uint64_t begin)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    wave_lds_sync();
+    const unsigned long long live_m = take >= 64 ? ~0ull : (1ull << take) - 1;
+    const uint32_t src = n - take + (lane < take ? lane : 0);
+    const float2 c = qc[src];
+    const uint32_t sidx = qidx[src];
+    wave_lds_sync();
+    n -= take;
+    const uint64_t s = begin + sidx;
+    const U4 pb = philox_draw_block(seed, scene_id, s >> 2, 2u + ((uint32_t)(s >> 1) & 1u));
+    const bool odd = (s & 1) != 0;
+    return evaluate_samples<PARKED>(sc, wq, odd ? pb.z : pb.x, odd ? pb.w : pb.y, c.x, c.y, seed, scene_id, s, live_m);
+}
+
+// ---- NEAR: hits among samples [begin, begin + count) of one scene, computed by one wave.  A lane owns one GROUP of four samples
+// per iteration (draw layout: c2d_math.hpp), so an iteration covers 256 consecutive samples.  begin and count are arbitrary (a
+// shard may start inside a group): positions outside [begin, begin + count) are masked, never drawn into the result.
+// The lane produces its four members back to back in straight-line code — the group's two blocks stay in registers for exactly
+// that long — and only the samples the centre pretest leaves undecided are queued (centre, offset); whenever 64 wait they are
+// evaluated, each drawing the block of its own second pair.  The form of round 2 (members one per pass of a rolled loop, blocks
+// in a lane-private LDS stash, the second pair's block drawn wave-wide for a pair of members as soon as ONE lane was undecided)
+// paid that block for nearly every pair on a sparse scene; this one is 1.35x faster on scenes whose samples are mostly ruled
+// out by their centre — the long tail of a dataset batch — and 5 % faster on the config-3 scene (four independent Box-Muller
+// chains per lane for the scheduler, no stash traffic) although that scene now draws 0.65 instead of 0.44 second-pair blocks
+// per sample; a scene in which EVERY sample collides is 16 % slower (one block per sample instead of one per two).  DESIGN.md §5.
 template <bool PARKED>
 C2D_DEV uint32_t wave_count_hits_near(const Scene& sc, uint64_t seed, uint64_t scene_id, uint64_t begin, uint32_t count,
                                       WaveQueue& wq)
 {
     auto& q = wq.near;
     const uint32_t lane = threadIdx.x & 63;
-    uint32_t hits = 0;    // wave-uniform (scalar) accumulator
-    uint32_t qn = 0;      // queued samples (wave-uniform)
-    uint32_t dense = 0;   // sub-iterations to evaluate in place after the pretest ruled nothing out
-    // (count < 2^31 — the callers cut work into far smaller chunks — keeps every offset below in 32 bits)
-    const uint64_t g0 = begin >> 2;                        // first group touched
-    const uint32_t base = (uint32_t)(begin & 3);           // position of sample `begin` inside it
-    const uint32_t end_pos = base + count;                 // this call's samples are positions [base, end_pos) from 4 * g0
+    uint32_t hits = 0, qn = 0;  // wave-uniform
+    const uint64_t g0 = begin >> 2;
+    const uint32_t base = (uint32_t)(begin & 3);
+    const uint32_t end_pos = base + count;
     const uint32_t n_groups = (end_pos + 3) >> 2;
-    auto stash = [&](uint32_t (&dst)[4][64], const U4& v) { dst[0][lane] = v.x; dst[1][lane] = v.y; dst[2][lane] = v.z; dst[3][lane] = v.w; };
-
-    uint32_t gi = 0;      // next group offset to open
-    bool flush = false;   // input exhausted: the loop body only drains the queue
-    for (;;) {
-        uint32_t lo = 0, hi = 0;
-        bool inner = false;   // every position of the iteration is in range
-        uint64_t g = 0;       // the lane's group
-        uint32_t sidx0 = 0;   // chunk offset of its member 0 (wraps only where masked)
-        if (gi < n_groups) {
-            // ---- open the next iteration: radius and angle blocks of its 64 groups
-            const uint32_t p0 = 4 * gi;                                   // position of the iteration's first sample
-            lo = p0 >= base ? 0u : base;                                   // (p0 < base only for the first iteration)
-            const uint32_t rem = end_pos - p0;
-            hi = rem < 256 ? rem : 256u;
-            inner = lo == 0 && hi == 256;
-            g = g0 + gi + lane;
-            sidx0 = p0 - base + 4 * lane;
-            stash(q.r, philox_draw_block(seed, scene_id, g, 0));
-            stash(q.a, philox_draw_block(seed, scene_id, g, 1));
-            gi += 64;
-        } else if (qn == 0) {
-            break;
-        } else {
-            flush = true;
-        }
-        uint32_t pz = 0, pw = 0;  // the odd member's words of block 2 (j = 1) / 3 (j = 3), left by the even member
-        bool have = false;
 #pragma nounroll
-        for (uint32_t j = 0; j < 4; j++) {
-            bool direct = false;  // evaluate this sub-iteration's samples straight from the registers
-            float dx = 0.0f, dy = 0.0f;
-            uint32_t w2r = 0, w2a = 0, sidx = 0;
-            unsigned long long live_m = 0;  // lanes whose sample counts
-            if (!flush) {
-                // ---- produce sub-iteration j: member j of the 64 groups
-                if (j == 2) have = false;
-                const uint32_t pos = 4 * lane + j;
-                const bool in_range = inner || (pos >= lo && pos < hi);
-                const unsigned long long in_m =
-                    inner ? wave_lanes() : (__builtin_amdgcn_ballot_w64(pos >= lo) & __builtin_amdgcn_ballot_w64(pos < hi));
-                const uint32_t rw = q.r[j][lane], aw = q.a[j][lane];
-                const bool odd = (j & 1) != 0;
-                sidx = sidx0 + j;
-                bool undecided = in_range;           // per lane, for control flow ...
-                unsigned long long m = in_m;          // ... and the same vote as a lane mask
-                if (dense) {  // every lane needs the full evaluation anyway
-                    dense--;
-                    C2D_MC_STAT(4, __popcll(in_m));
-                    sample_centre(sc, rw, aw, dx, dy);
-                    live_m = in_m;
-                    direct = true;
-                } else {
+    for (uint32_t gi = 0; gi < n_groups; gi += 64) {
+        const uint32_t p0 = 4 * gi;
+        const uint32_t lo = p0 >= base ? 0u : base;
+        const uint32_t rem = end_pos - p0;
+        const uint32_t hi = rem < 256 ? rem : 256u;
+        const bool inner = lo == 0 && hi == 256;  // every position of the iteration is this call's
+        const uint64_t g = g0 + gi + lane;
+        const uint32_t sidx0 = p0 - base + 4 * lane;
+        const U4 r = philox_draw_block(seed, scene_id, g, 0), a = philox_draw_block(seed, scene_id, g, 1);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t pos = 4 * lane + (uint32_t)j;
+            bool undecided = inner || (pos >= lo && pos < hi);
+            unsigned long long m = inner ? wave_lanes() : (__builtin_amdgcn_ballot_w64(pos >= lo) & __builtin_amdgcn_ballot_w64(pos < hi));
+            const uint32_t rw = u4_word(r, j), aw = u4_word(a, j);
 #ifndef C2D_MC_NO_PRETEST
-                    if (sc.use_x0) {  // the radius word alone may prove the miss
-                        const bool c = rw < sc.x0;
-                        undecided = undecided && c;
-                        m &= __builtin_amdgcn_ballot_w64(c);
-                    }
-                    if (m == 0ull) continue;
+            if (sc.use_x0) {  // the radius word alone may prove the miss
+                const bool c = rw < sc.x0;
+                undecided = undecided && c;
+                m &= __builtin_amdgcn_ballot_w64(c);
+            }
 #endif
-                    C2D_MC_STAT(4, __popcll(m));
-                    sample_centre(sc, rw, aw, dx, dy);
+            if (m == 0ull) continue;
+            C2D_MC_STAT(4, __popcll(m));
+            float dx, dy;
+            sample_centre(sc, rw, aw, dx, dy);
 #ifndef C2D_MC_NO_PRETEST
-                    unsigned long long miss_m;
-                    const bool miss = centre_pretest(sc, dx, dy, miss_m);  // (every lane votes: no short-circuit around it)
-                    undecided = undecided && !miss;
-                    m &= ~miss_m;
+            unsigned long long miss_m;
+            const bool miss = centre_pretest(sc, dx, dy, miss_m);  // (every lane votes: no short-circuit around it)
+            undecided = undecided && !miss;
+            m &= ~miss_m;
+            if (m == 0ull) continue;  // 64 certain misses
 #endif
-                    if (m == 0ull) continue;  // 64 certain misses
-                    if (m == wave_lanes()) dense = C2D_MC_PRETEST_HOLDOFF;
-                }
-                if (!have) {
-                    const U4 pb = philox_draw_block(seed, scene_id, g, 2 + (j >> 1));
-                    have = true;
-                    w2r = odd ? pb.z : pb.x;
-                    w2a = odd ? pb.w : pb.y;
-                    pz = pb.z;
-                    pw = pb.w;
-                } else {  // the even member of the pair computed the block
-                    w2r = pz;
-                    w2a = pw;
-                }
-                if (!direct) {
-                    if (undecided) {
-                        const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                        q.cw[slot] = make_float4(dx, dy, __uint_as_float(w2r), __uint_as_float(w2a));
-                        q.idx[slot] = sidx;
-                    }
-                    qn += (uint32_t)__popcll(m);
-                    if (qn < 64) continue;
-                }
+            if (undecided) {
+                const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                q.c[slot] = make_float2(dx, dy);
+                q.idx[slot] = sidx0 + (uint32_t)j;
             }
-            // ---- evaluate 64 samples: this sub-iteration's (direct) or queued ones (a full wave of them, or what is
-            // left at the end).  Lanes read slots that other lanes of this wave wrote: LDS operations of a wave complete
-            // in order, the fence pairs only stop the compiler from reordering the reads above the writes and later
-            // writes above the reads (no instruction is emitted)
-            if (!direct) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const uint32_t take = qn < 64 ? qn : 64;
-                live_m = take >= 64 ? ~0ull : (1ull << take) - 1;
-                const uint32_t src = qn - take + (lane < take ? lane : 0);
-                const float4 e = q.cw[src];
-                sidx = q.idx[src];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                qn -= take;
-                dx = e.x;
-                dy = e.y;
-                w2r = __float_as_uint(e.z);
-                w2a = __float_as_uint(e.w);
-            }
-            hits += evaluate_samples<PARKED>(sc, wq, w2r, w2a, dx, dy, seed, scene_id, begin + sidx, live_m);
-            if (flush) break;
+            qn += (uint32_t)__popcll(m);
         }
+        while (qn >= 64) hits += evaluate_queued<PARKED>(sc, wq, q.c, q.idx, qn, 64, seed, scene_id, begin);
     }
+    if (qn) hits += evaluate_queued<PARKED>(sc, wq, q.c, q.idx, qn, qn, seed, scene_id, begin);
     return hits;
 }
 
@@ -854,24 +795,7 @@ C2D_DEV uint32_t wave_count_hits_far(const Scene& sc, uint64_t seed, uint64_t sc
             un += (uint32_t)__popcll(m);
         }
         // ---- stage 3: 64 undecided samples, or what is left once nothing more can come
-        if (un >= 64 || (drained && cn == 0 && un)) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const uint32_t take = un < 64 ? un : 64;
-            const unsigned long long live_m = take >= 64 ? ~0ull : (1ull << take) - 1;
-            const uint32_t src = un - take + (lane < take ? lane : 0);
-            const float2 c = q.und_c[src];
-            const uint32_t sidx = q.und_idx[src];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            un -= take;
-            const uint64_t s = begin + sidx;
-            const U4 pb = philox_draw_block(seed, scene_id, s >> 2, 2u + ((uint32_t)(s >> 1) & 1u));
-            const bool odd = (s & 1) != 0;
-            hits += evaluate_samples<PARKED>(sc, wq, odd ? pb.z : pb.x, odd ? pb.w : pb.y, c.x, c.y, seed, scene_id, s, live_m);
-        }
+        if (un >= 64 || (drained && cn == 0 && un)) hits += evaluate_queued<PARKED>(sc, wq, q.und_c, q.und_idx, un, un < 64 ? un : 64u, seed, scene_id, begin);
         if (drained && cn == 0 && un == 0) break;
     }
     return hits;
