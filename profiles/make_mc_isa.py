@@ -39,7 +39,8 @@ with max_samples 120 000, default batch = 1e5 data points with max_samples 4 020
 
 Every kernel: closed-form full evaluation (model_gap), the fields of the vertex arithmetic behind it (robot vertices, parallel-axis
 certificates) parked in LDS.  Adaptive kernels: the other evaluation-only scene fields parked too, 7 waves per SIMD (72 VGPRs).
-mc_pair_kernel: those fields in registers (77 VGPRs).
+mc_pair_kernel: those fields in registers (73 VGPRs).  Near scenes run the four members of a group in straight-line code since the last
+change of the round (no LDS stash; LDS per wave 4.2 KB), which is also why the adaptive kernels now spill 2-4 dwords instead of 16-17.
 
 ```""")
 print(digest([]))
@@ -82,6 +83,8 @@ print("""```
 | ... queueing from 32 / 48 survivors, or always | 0.556 / 0.557 / 0.594 (when also applied to mc_pair_kernel) | 377.0 / 377.9 / 379.8 | 38.8 / 38.8 / 39.1 |
 | closed-form full evaluation (`model_gap`; vertex arithmetic only behind a thin result, no survivor queue), 6 waves (another box: the row above reads 0.549 / 383.5 / 39.2 there) | **0.411** | 335-337 | 33.1-33.3 |
 | ... adaptive kernels at 5 / 7 waves per SIMD: **7 shipped** | 0.412 | 349 / **324-325** | 34.7 / **32.5** |
+| + near scenes: four members per lane in straight-line code, only undecided samples queued, the second pair's block drawn by the evaluating lane: **shipped** | **0.391-0.400** | **314-317** | **30.4-30.7** |
+| ... mc_pair_kernel at 7 waves, adaptive kernels at 6 / 8 waves | 0.395 | 318.6 / 318.7 | 30.7 / 31.2 |
 
 Reading: the spills of round 2 (and the larger ones the certificates added) were HARMLESS - removing every scratch access from the
 sample loops changes the config-4 shard by less than 0.5 % - and the obvious cure, scalar registers, is a loss on this kernel because
