@@ -189,8 +189,7 @@ C2D_DEV int bin_variant(int rows_a, int rows_b) { return ((rows_a + 3) >> 2) * 4
 // One tile (64 pairs) of one bin.  SYM: only the instances with equal row classes on both sides are compiled (the padded
 // layouts of c2d_sat_poly_pairs_rows are one bin with rows_a == rows_b).
 template <bool SYM>
-C2D_DEV void binned_tile(const BinDesc& D, uint32_t tile_in_bin, unsigned long long* __restrict__ d_count, unsigned long long* __restrict__ words,
-                         uint32_t* __restrict__ async_err)
+C2D_DEV uint32_t binned_tile(const BinDesc& D, uint32_t tile_in_bin, uint32_t* __restrict__ async_err)   // -> colliding pairs of the tile (wave-uniform)
 {
     constexpr int KM = C2D_POLY_KMAX;
     __shared__ __attribute__((aligned(16))) float2 s_slot[kBinSlots][kSlotF2];
@@ -321,26 +320,44 @@ C2D_DEV void binned_tile(const BinDesc& D, uint32_t tile_in_bin, unsigned long l
     }
     const bool collide = in && !sep;
     if (in) D.out[p0 + lane] = collide ? (uint8_t)1 : (uint8_t)0;
-    if (d_count) wave_count_arrive_total2((uint32_t)__popcll(__ballot(collide)), d_count, words);
+    return (uint32_t)__popcll(__ballot(collide));
 }
 static_assert(kCountWords2Bytes == C2D_COUNT_WORDS2_BYTES, "workspace size of the two-level count");
 
 // every bin of a batch in one launch: a u32 per tile names the bin
+// A wave takes kTilesPerWave consecutive tiles and arrives at the count once: with one tile per wave the returning atomic of the
+// count — a round trip to the memory side at the end of a life of a few microseconds — cost 5 % of the launch on the config-5 bins
+// and 14 % on bins of triangles (tests/tools/binned_bench.py: 0.279 against 0.265 ms, 0.144 against 0.126 ms).  Two tiles per
+// wave, interleaved A/B on one box, 1e7 pairs with the count: config-5 bins 0.269 -> 0.258 ms, K = 3 / 8 / 12 / 16 only 0.156 ->
+// 0.144 / 0.229 -> 0.205 / 0.326 -> 0.310 / 0.429 -> 0.421 ms (faster even without the count: the second tile's loads start while
+// the first one's stores drain); four tiles are no better (0.256-0.270 / 0.141 / 0.208 / 0.325 / 0.412-0.426), eight are worse.
+#ifndef C2D_POLY_TILES_PER_WAVE
+#define C2D_POLY_TILES_PER_WAVE 2
+#endif
+constexpr uint32_t kTilesPerWave = C2D_POLY_TILES_PER_WAVE;
 __global__ __launch_bounds__(64, 5) void sat_poly_binned_kernel(const BinDesc* __restrict__ bins, const uint32_t* __restrict__ tile_bin,
-                                                               uint32_t tile_offset, unsigned long long* __restrict__ d_count,
+                                                               uint32_t tile_begin, uint32_t tile_end, unsigned long long* __restrict__ d_count,
                                                                unsigned long long* __restrict__ words, uint32_t* __restrict__ async_err)
 {
-    const uint32_t tile = blockIdx.x + tile_offset;
-    const uint32_t bin = __builtin_amdgcn_readfirstlane(tile_bin[tile]);
-    const BinDesc D = bins[bin];
-    binned_tile<false>(D, tile - D.tile0, d_count, words, async_err);
+    uint32_t total = 0;
+#pragma nounroll
+    for (uint32_t i = 0; i < kTilesPerWave; i++) {
+        const uint32_t tile = tile_begin + blockIdx.x * kTilesPerWave + i;
+        if (tile >= tile_end) break;
+        const uint32_t bin = __builtin_amdgcn_readfirstlane(tile_bin[tile]);
+        const BinDesc D = bins[bin];
+        total += binned_tile<false>(D, tile - D.tile0, async_err);
+        if (kTilesPerWave > 1) __syncthreads();  // (single-wave block: a wave-level fence) the next tile reuses the LDS slots
+    }
+    if (d_count) wave_count_arrive_total2(total, d_count, words);
 }
 
 // ONE bin whose descriptor travels in the kernel arguments: the padded layouts of c2d_sat_poly_pairs_rows (no table, no upload)
 __global__ __launch_bounds__(64, 5) void sat_poly_onebin_kernel(BinDesc D, uint32_t tile_offset, unsigned long long* __restrict__ d_count,
                                                                unsigned long long* __restrict__ words, uint32_t* __restrict__ async_err)
 {
-    binned_tile<true>(D, blockIdx.x + tile_offset, d_count, words, async_err);
+    const uint32_t c = binned_tile<true>(D, blockIdx.x + tile_offset, async_err);
+    if (d_count) wave_count_arrive_total2(c, d_count, words);
 }
 
 // host entry used by c2d_poly.hip: rows_a == rows_b == rows, planes rows * n apart
@@ -719,9 +736,11 @@ int c2d_sat_poly_pairs_binned(c2d_ctx* ctx, const c2d_poly_bins* bins, unsigned 
     DeviceGuard g(ctx->device);
     hipStream_t s = (hipStream_t)stream;
     if (int rc = workspace_acquire(ctx, s, d_count != nullptr)) return rc;
-    for (size_t t0 = 0; t0 < bins->n_tiles; t0 += (size_t)kMaxGrid) {
-        const size_t grid = std::min(bins->n_tiles - t0, (size_t)kMaxGrid);
-        hipLaunchKernelGGL(sat_poly_binned_kernel, dim3((unsigned)grid), dim3(64), 0, s, bins->d_table, bins->d_tile_bin, (uint32_t)t0, d_count,
+    const size_t per_launch = (size_t)kMaxGrid * kTilesPerWave;
+    for (size_t t0 = 0; t0 < bins->n_tiles; t0 += per_launch) {
+        const size_t t1 = std::min(bins->n_tiles, t0 + per_launch);
+        const size_t grid = (t1 - t0 + kTilesPerWave - 1) / kTilesPerWave;
+        hipLaunchKernelGGL(sat_poly_binned_kernel, dim3((unsigned)grid), dim3(64), 0, s, bins->d_table, bins->d_tile_bin, (uint32_t)t0, (uint32_t)t1, d_count,
                            ctx->d_count_words2, ctx->d_async_err);
     }
     C2D_LAUNCH_CHECK(ctx);
