@@ -327,8 +327,14 @@ template <int KM, int MIN_WAVES, bool FULL>
 static void launch_poly(hipStream_t s, const float* d_vx, const float* d_vy, const uint8_t* d_k, size_t n, int rows, uint8_t* d_out,
                         unsigned long long* d_count, unsigned long long* words, uint32_t* async_err)
 {
+    // tiles per wave: 2 pay in the binned kernel (c2d_poly_binned.hip); here, at the HBM ceiling of the padded bytes, 2 and 4 change nothing
+    // (config 5: 0.410 / 0.414 / 0.422 ms, K <= 8 in 8 rows: 0.264 / 0.265 / 0.270 ms)
+#ifndef C2D_POLY_PADDED_TILES_PER_WAVE
+#define C2D_POLY_PADDED_TILES_PER_WAVE 1
+#endif
     const size_t n_tiles = (n + 63) / 64;
-    const int grid = (int)(n_tiles < (size_t)kMaxGrid ? n_tiles : (size_t)kMaxGrid);
+    const size_t want = (n_tiles + C2D_POLY_PADDED_TILES_PER_WAVE - 1) / C2D_POLY_PADDED_TILES_PER_WAVE;  // the kernel strides by the grid
+    const int grid = (int)(want < (size_t)kMaxGrid ? want : (size_t)kMaxGrid);
     hipLaunchKernelGGL((sat_poly_kernel<KM, MIN_WAVES, FULL>), dim3(grid), dim3(64), 0, s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words, async_err);
 }
 
