@@ -450,6 +450,10 @@ def main() -> None:
         mel = shd.max_over_ranks(m1 - m0, dev)
         mc_kernel_ms = e0.elapsed_time(e1) / args.mc_reps
         p = float(hits.item()) / (S * world * args.mc_reps)
+        # hits of ONE step on this rank's range (every rep repeats the same samples), for the oracle comparison below
+        mc_hits_one_step = int(hits.item()) // args.mc_reps if world == 1 else None
+        if world == 1 and int(hits.item()) != mc_hits_one_step * args.mc_reps:
+            raise SystemExit("bench: the Monte-Carlo reps of one sample range gave different hit counts")
         mc = {"metric": "mc_samples_per_s", "value": S * world * args.mc_reps / mel, "samples_per_gpu": S, "reps": args.mc_reps,
               "kernel_ms": round(mc_kernel_ms, 4), "probability": p, "scene": "config3: robot 4.07x1.74 at (3,1) th=0.6, obstacle 2x1, sigma=(.3,.3,.2,0,0)",
               "bound": "valu", "note": "~0 HBM bytes per sample; VALU/transcendental bound (DESIGN.md)"}
@@ -726,16 +730,26 @@ def main() -> None:
                         "sample": f"all {n} pairs of the workload x {reps} passes ({cel:.1f} s), OpenMP", "parity": parity["config2"]}
         del host_planes
         if mc is not None:
-            ms, done, h = 4_000_000, 0, 0
+            # consecutive sample ranges of the same stream; the range boundaries are chosen so that the walk passes through
+            # done == S exactly, where the oracle's running hit count must EQUAL the GPU's for one mc_step (config 3 at its
+            # stated size, hit for hit: ccp.cu:135-139 with utils.cu:144-184 per sample)
+            ms, done, h, h_at_s = 4_000_000, 0, 0, None
             c0 = time.perf_counter()
-            while True:  # consecutive sample ranges of the same stream
-                h += oracle.mc_pair(sc["robot_w"], sc["robot_h"], sc["pos"], sc["pose"], sc["std_dev"], 1234, 0, done, ms)
-                done += ms
-                if time.perf_counter() - c0 >= budget:
+            while True:
+                m = min(ms, S - done) if done < S else ms
+                h += oracle.mc_pair(sc["robot_w"], sc["robot_h"], sc["pos"], sc["pose"], sc["std_dev"], 1234, 0, done, m)
+                done += m
+                if done == S:
+                    h_at_s = h
+                if done >= S and time.perf_counter() - c0 >= budget:  # (never stops short of S: the parity check needs all of it)
                     break
             cel = time.perf_counter() - c0
+            mc["parity"] = f"hits equal on {S} of {S} samples ({mc_hits_one_step} hits)"
+            if h_at_s != mc_hits_one_step:
+                raise SystemExit(f"PARITY FAILURE: Monte-Carlo hit count over the first {S} samples: GPU {mc_hits_one_step}, CPU oracle {h_at_s}")
             mc["cpu_baseline"] = {"value": done / cel, "unit": "samples/s", "cores": oracle.num_threads(), "kind": "port",
-                                  "sample": f"first {done} samples of the same stream ({cel:.1f} s), OpenMP", "probability": h / done}
+                                  "sample": f"first {done} samples of the same stream ({cel:.1f} s), OpenMP", "probability": h / done,
+                                  "parity": mc["parity"]}
         if poly_keep is not None:  # config 5: every boolean of the 16-row batch
             hvx, hvy, hk, hout = poly_keep
             ref, ref_cnt = oracle.sat_poly_pairs(hvx, hvy, hk)
