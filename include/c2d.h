@@ -382,6 +382,63 @@ int c2d_sample_scenes(c2d_ctx* ctx, const Pose* d_poses, uint32_t num_poses,
                       float robot_h, float spread, uint64_t seed, uint64_t scene_id_base,
                       size_t n_scenes, PositionWithVarAndPoseIdx* d_scenes, c2d_stream stream);
 
+/* ---- Monte-Carlo collision probability for convex polygons -----------------------
+ * The reference's README (README.md:3) says its code "can easily be extended to handle arbitrary
+ * convex 2D shapes"; its own functions stop at rectangles (sample_rectangle utils.cu:144-157,
+ * convex_collide utils.cu:159-184).  These two entry points are that extension of c2d_mc_pair /
+ * c2d_mc_scenes, with the same random stream, draw order, sample sharding and stopping rule:
+ *
+ *   robot     a polygon in its own frame, rotated by theta and moved to pos with the arithmetic of
+ *             rot_trans_rectangle (utils.cu:132-142; ccp.cu:132-133);
+ *   obstacle  a polygon about the origin (ccp.cu:128).  A sample draws the five normals of
+ *             utils.cu:146-150 in that order and applies them as sample_rectangle does: dw, dh change
+ *             the SHAPE first — the obstacle frame's x / y coordinates are scaled by (1 + dw), (1 + dh),
+ *             so StdDev.width / .height are RELATIVE standard deviations here (a w x h rectangle given
+ *             as a 4-gon with sigma_w / w, sigma_h / h has the distribution of the reference's sample,
+ *             utils.cu:152-155) — then the shape is rotated by dtheta about the origin and moved by
+ *             (dx, dy) (utils.cu:156);
+ *   test      the projection / strict-< interval test of utils.cu:172-180 on the true normals of all
+ *             ka + kb edges, exactly as c2d_sat_poly_pairs.
+ *
+ * With sigma_w = sigma_h = 0 a rectangle given as a 4-gon gets, sample for sample, the very vertices
+ * c2d_mc_pair gives it; the two tests then differ only in the scale of their axes (edge vector there,
+ * normal here), which can move a boolean only for a sample within an ulp of touching.
+ * Vertex order may be clockwise or counter-clockwise; 1 <= k <= C2D_POLY_KMAX (k = 1, 2: a point, a
+ * segment).  The certain-miss shortcuts require finite parameters below 1e15 in magnitude, as for
+ * c2d_mc_pair; outside that domain every sample is evaluated in full with the all-bit-patterns test. */
+typedef struct c2d_polygon {
+    uint32_t k;                   /* vertices used */
+    float x[C2D_POLY_KMAX];
+    float y[C2D_POLY_KMAX];
+} c2d_polygon;
+
+/* c2d_mc_poly_pair: one polygon scene, sample-parallel (c2d_mc_pair's contract: samples sample_begin ..
+ * sample_begin + n_samples - 1 of stream (seed, scene_id); *d_hits is incremented).  robot, obstacle,
+ * pos and std_dev are host pointers read before the call returns. */
+int c2d_mc_poly_pair(c2d_ctx* ctx, const c2d_polygon* robot, const Position* pos, float robot_theta,
+                     const c2d_polygon* obstacle, const StdDev* std_dev, uint64_t seed, uint64_t scene_id,
+                     uint64_t sample_begin, uint64_t n_samples, unsigned long long* d_hits, c2d_stream stream);
+
+/* One entry of the polygon scene table: what Pose {width, height, theta} (utils.cu:91-94) is to the
+ * rectangle dataset — the robot's rotation in the scene and the obstacle's shape. */
+typedef struct c2d_poly_pose {
+    float theta;
+    c2d_polygon obstacle;
+} c2d_poly_pose;
+
+/* c2d_mc_poly_scenes: c2d_mc_scenes for polygon scenes.  `base` carries the scenes, tables of standard
+ * deviations, schedule, stop rule, seeds and outputs exactly as for c2d_mc_scenes; its d_poses, num_poses,
+ * robot_w and robot_h are ignored and replaced by d_poly_poses / num_poly_poses (device table indexed by
+ * the rows' pose_idx) and the robot polygon (host pointer).  A vertex count outside 1..C2D_POLY_KMAX in the
+ * device table is clamped and reported by the next c2d_stream_synchronize / c2d_ctx_check_async. */
+typedef struct c2d_mc_poly_scenes_args {
+    c2d_mc_scenes_args base;
+    const c2d_polygon* robot;            /* host */
+    const c2d_poly_pose* d_poly_poses;   /* device c2d_poly_pose[num_poly_poses] */
+    uint32_t num_poly_poses;
+} c2d_mc_poly_scenes_args;
+int c2d_mc_poly_scenes(c2d_ctx* ctx, const c2d_mc_poly_scenes_args* args, c2d_stream stream);
+
 /* ---- multi-GPU aggregation ----------------------------------------------------
  * New work (the reference is single-GPU, compute_collision_probability.cu:212-251): pairs,
  * scenes and Monte-Carlo sample ranges shard over the GPUs of a node with no exchange on

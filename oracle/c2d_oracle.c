@@ -34,11 +34,8 @@
 #include <omp.h>
 #endif
 
-#include "../include/utils.h"
-
-#define C2D_MC_SMALL_BATCH 1000
-#define C2D_MC_LARGE_BATCH 100000
-#define C2D_MC_SWITCH_AT 20000
+/* the boundary types and schedule constants (declarations only: the oracle links nothing of the product) */
+#include "../include/c2d.h"
 
 /* C2D_ORACLE_FMAD selects how the reference's two-product sums a*x + b*y (utils.cu:139-140, :173-174) are rounded:
  *   0 (canonical, default)  fadd(fmul(a,x), fmul(b,y))       — what the c2d kernels compute;
@@ -618,6 +615,153 @@ unsigned long long c2d_oracle_mc_scenes(const Pose* poses, uint32_t num_poses, c
             rows[g].x = pos.x;
             rows[g].y = pos.y;
             rows[g].cp = (float)k / (float)n; /* utils.cu:214 */
+            rows[g].var_idx = scenes[g].var_idx;
+            rows[g].pose_idx = scenes[g].pose_idx;
+        }
+        total += n;
+    }
+    return total;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Monte-Carlo over convex polygons                                          */
+/* ------------------------------------------------------------------------ */
+/* README.md:3 of the reference: "can easily be extended to handle arbitrary convex 2D shapes".  The reference itself
+ * stops at rectangles (sample_rectangle utils.cu:144-157, convex_collide utils.cu:159-184); what follows is that
+ * extension, stated once here and implemented independently by the kernels (csrc/c2d_mc_poly.hip):
+ *   - the robot is a polygon in its own frame, rotated by theta and moved to pos with the arithmetic of
+ *     rot_trans_rectangle (utils.cu:132-142; ccp.cu:132-133);
+ *   - the obstacle is a polygon about the origin (ccp.cu:128); a sample draws the reference's five normals in the
+ *     reference's order (utils.cu:146-150) and applies them as sample_rectangle does: dw, dh change the SHAPE first —
+ *     for a rectangle the half extents grow by dw/2, dh/2 (utils.cu:152-155); for a polygon the obstacle frame's x / y
+ *     coordinates are scaled by (1 + dw), (1 + dh), i.e. StdDev.width / .height are RELATIVE here (a w x h rectangle
+ *     given as a 4-gon with sigma_w / w, sigma_h / h has the distribution of the reference's sample) — then the shape
+ *     is rotated by dtheta about the origin and moved by (dx, dy) (utils.cu:156);
+ *   - the collision test is the projection / strict-< interval test of utils.cu:172-180 on the TRUE normals of all
+ *     ka + kb edges (c2d_oracle_poly_collide above; the edge-as-axis shortcut of utils.cu:170-171 is only valid for
+ *     rectangles).
+ * With sigma_w = sigma_h = 0 the scale factors are exactly 1 and a rectangle given as a 4-gon gets the very vertices
+ * c2d_oracle_mc_pair gives it; the two tests then differ only in the scale of their axes (edge vector against normal). */
+/* robot placement: rot_trans_rectangle (utils.cu:132-142) applied to every vertex of a polygon */
+void c2d_oracle_place_polygon(const c2d_polygon* in, float dx, float dy, float dt, float* ox, float* oy)
+{
+    float c, s;
+    c2d_oracle_sincosf(dt, &s, &c);
+    for (uint32_t k = 0; k < in->k; k++) {
+        float x = in->x[k], y = in->y[k];
+        ox[k] = dot2(c, x, -s, y) + dx;
+        oy[k] = dot2(s, x, c, y) + dy;
+    }
+}
+
+/* utils.cu:144-157 for a polygon, the five normals passed in */
+void c2d_oracle_sample_polygon(const c2d_polygon* in, const StdDev* sd, const float n[5], float* ox, float* oy)
+{
+    float dx = n[0] * sd->x;
+    float dy = n[1] * sd->y;
+    float dt = n[2] * sd->theta;
+    float dw = n[3] * sd->width;
+    float dh = n[4] * sd->height;
+    float fx = 1.0f + dw, fy = 1.0f + dh; /* utils.cu:152-155: the shape changes before it is rotated and moved */
+    float c, s;
+    c2d_oracle_sincosf(dt, &s, &c);
+    for (uint32_t k = 0; k < in->k; k++) {
+        float x = fx * in->x[k], y = fy * in->y[k];
+        ox[k] = dot2(c, x, -s, y) + dx; /* utils.cu:139 */
+        oy[k] = dot2(s, x, c, y) + dy;  /* utils.cu:140 */
+    }
+}
+
+static inline int poly_scene_sample(const float* rx, const float* ry, int ka, const c2d_polygon* obstacle, const StdDev* sd,
+                                    uint64_t seed, uint64_t scene_id, uint64_t sample, DrawCache* cache)
+{
+    float n[5], unused, ox[C2D_POLY_KMAX], oy[C2D_POLY_KMAX];
+    uint32_t w[6];
+    draw_words_cached(cache, seed, scene_id, sample, w);
+    c2d_oracle_box_muller(w[0], w[1], &n[0], &n[1]);
+    c2d_oracle_box_muller(w[2], w[3], &n[2], &n[3]);
+    c2d_oracle_box_muller(w[4], w[5], &n[4], &unused);
+    c2d_oracle_sample_polygon(obstacle, sd, n, ox, oy);
+    return c2d_oracle_poly_collide(rx, ry, ka, ox, oy, (int)obstacle->k); /* ccp.cu:138 */
+}
+
+static int polygon_ok(const c2d_polygon* p) { return p && p->k >= 1 && p->k <= C2D_POLY_KMAX; }
+
+/* hits among samples [sample_begin, sample_begin + n_samples) of one polygon scene (ccp.cu:119-139); ~0 on a bad count */
+unsigned long long c2d_oracle_mc_poly_pair(const c2d_polygon* robot, const Position* pos, float robot_theta,
+                                           const c2d_polygon* obstacle, const StdDev* sd, uint64_t seed,
+                                           uint64_t scene_id, uint64_t sample_begin, uint64_t n_samples)
+{
+    if (!polygon_ok(robot) || !polygon_ok(obstacle)) return ~0ull;
+    float rx[C2D_POLY_KMAX], ry[C2D_POLY_KMAX];
+    c2d_oracle_place_polygon(robot, pos->x, pos->y, robot_theta, rx, ry); /* ccp.cu:132-133 */
+    unsigned long long hits = 0;
+#pragma omp parallel reduction(+ : hits)
+    {
+        DrawCache cache = {~0ull, 0, {{0}}};
+#pragma omp for schedule(static)
+        for (long long i = 0; i < (long long)n_samples; i++)
+            hits += (unsigned)poly_scene_sample(rx, ry, (int)robot->k, obstacle, sd, seed, scene_id, sample_begin + (uint64_t)i, &cache);
+    }
+    return hits;
+}
+
+/* the sampled obstacle of one sample (debug / geometry parity) */
+void c2d_oracle_mc_poly_sampled(const c2d_polygon* obstacle, const StdDev* sd, uint64_t seed, uint64_t scene_id,
+                                uint64_t sample, float* ox, float* oy)
+{
+    float n[5];
+    c2d_oracle_normals5(seed, scene_id, sample, n);
+    c2d_oracle_sample_polygon(obstacle, sd, n, ox, oy);
+}
+
+/* The adaptive loop of c2d_oracle_mc_scenes for polygon scenes: the table holds (robot rotation, obstacle shape) where
+ * the reference's holds Pose {width, height, theta}; rows, schedule and stop rule are the same (ccp.cu:276-332).
+ * Vertex counts outside 1..C2D_POLY_KMAX are clamped (the kernels do the same and report the error). */
+unsigned long long c2d_oracle_mc_poly_scenes(const c2d_polygon* robot, const c2d_poly_pose* poses, uint32_t num_poses,
+                                             const StdDev* std_devs, uint32_t num_std_devs,
+                                             const PositionWithVarAndPoseIdx* scenes, size_t n_scenes,
+                                             const float* accuracy_bins, const float* bin_accuracy,
+                                             uint32_t n_accuracy_bins, uint32_t max_samples, uint64_t seed,
+                                             uint64_t scene_id_base, uint32_t small_batch, uint32_t large_batch,
+                                             uint32_t switch_at, uint32_t* hits_out, uint32_t* n_used_out,
+                                             PoseCPVarAndPoseIdx* rows)
+{
+    if (!small_batch && !large_batch && !switch_at) {
+        small_batch = C2D_MC_SMALL_BATCH; large_batch = C2D_MC_LARGE_BATCH; switch_at = C2D_MC_SWITCH_AT;
+    }
+    unsigned long long total = 0;
+    (void)num_poses;
+    (void)num_std_devs;
+    c2d_polygon rob = *robot;
+    rob.k = rob.k < 1 ? 1 : (rob.k > C2D_POLY_KMAX ? C2D_POLY_KMAX : rob.k);
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : total)
+    for (long long g = 0; g < (long long)n_scenes; g++) {
+        int pose_idx = (int)scenes[g].pose_idx; /* ccp.cu:121 */
+        int sd_idx = (int)scenes[g].var_idx;    /* ccp.cu:122 */
+        c2d_poly_pose pp = poses[pose_idx];
+        pp.obstacle.k = pp.obstacle.k < 1 ? 1 : (pp.obstacle.k > C2D_POLY_KMAX ? C2D_POLY_KMAX : pp.obstacle.k);
+        StdDev sd = std_devs[sd_idx];
+        float rx[C2D_POLY_KMAX], ry[C2D_POLY_KMAX];
+        c2d_oracle_place_polygon(&rob, scenes[g].x, scenes[g].y, pp.theta, rx, ry);
+        uint64_t sid = scene_id_base + (uint64_t)g;
+        uint32_t n = 0, k = 0;
+        DrawCache cache = {~0ull, 0, {{0}}};
+        while (n < max_samples) {
+            uint32_t nb = n < switch_at ? small_batch : large_batch;
+            for (uint32_t i = 0; i < nb; i++)
+                k += (uint32_t)poly_scene_sample(rx, ry, (int)rob.k, &pp.obstacle, &sd, seed, sid, (uint64_t)n + i, &cache);
+            n += nb;
+            float slack = c2d_oracle_calc_slack(n, k);
+            float p = (float)k / (float)n;
+            if (slack <= bin_accuracy[c2d_oracle_get_bin(p, accuracy_bins, n_accuracy_bins)]) break;
+        }
+        hits_out[g] = k;
+        n_used_out[g] = n;
+        if (rows) {
+            rows[g].x = scenes[g].x;
+            rows[g].y = scenes[g].y;
+            rows[g].cp = (float)k / (float)n;
             rows[g].var_idx = scenes[g].var_idx;
             rows[g].pose_idx = scenes[g].pose_idx;
         }

@@ -31,6 +31,12 @@ class StdDev(C.Structure):
                 ("width", C.c_float), ("height", C.c_float)]
 
 
+class Polygon(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("x", C.c_float * KMAX), ("y", C.c_float * KMAX)]
+
+
+POLY_DT = np.dtype([("k", "<u4"), ("x", "<f4", (KMAX,)), ("y", "<f4", (KMAX,))])
+POLY_POSE_DT = np.dtype([("theta", "<f4"), ("obstacle", POLY_DT)])
 POSE_DT = np.dtype([("width", "<f4"), ("height", "<f4"), ("theta", "<f4")])
 STD_DT = np.dtype([("x", "<f4"), ("y", "<f4"), ("theta", "<f4"), ("width", "<f4"), ("height", "<f4")])
 SCENE_DT = np.dtype([("x", "<f4"), ("y", "<f4"), ("var_idx", "<f4"), ("pose_idx", "<f4")])
@@ -90,6 +96,13 @@ def lib() -> C.CDLL:
         L.c2d_oracle_mc_pair.argtypes = [C.c_float, C.c_float, C.POINTER(Position), C.POINTER(Pose),
                                          C.POINTER(StdDev), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
         L.c2d_oracle_mc_scenes.restype = C.c_ulonglong
+        L.c2d_oracle_mc_poly_pair.restype = C.c_ulonglong
+        L.c2d_oracle_mc_poly_pair.argtypes = [C.POINTER(Polygon), C.POINTER(Position), C.c_float, C.POINTER(Polygon),
+                                              C.POINTER(StdDev), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
+        L.c2d_oracle_mc_poly_scenes.restype = C.c_ulonglong
+        L.c2d_oracle_place_polygon.argtypes = [C.POINTER(Polygon), C.c_float, C.c_float, C.c_float, fp, fp]
+        L.c2d_oracle_sample_polygon.argtypes = [C.POINTER(Polygon), C.POINTER(StdDev), fp, fp, fp]
+        L.c2d_oracle_mc_poly_sampled.argtypes = [C.POINTER(Polygon), C.POINTER(StdDev), C.c_uint64, C.c_uint64, C.c_uint64, fp, fp]
         _lib = L
     return _lib
 
@@ -276,6 +289,74 @@ def get_bin(p, bins) -> int:
 def mc_pair(robot_w, robot_h, pos, pose, sd, seed, scene_id, sample_begin, n_samples) -> int:
     return int(lib().c2d_oracle_mc_pair(robot_w, robot_h, C.byref(Position(*pos)), C.byref(Pose(*pose)),
                                         C.byref(StdDev(*sd)), seed, scene_id, sample_begin, n_samples))
+
+
+def polygon(xs, ys=None) -> Polygon:
+    """A Polygon from vertex coordinates (xs, ys) or from one POLY_DT record."""
+    if ys is None:
+        rec = xs
+        xs, ys = rec["x"][:int(rec["k"])], rec["y"][:int(rec["k"])]
+    xs, ys = _f32(xs), _f32(ys)
+    assert 1 <= len(xs) == len(ys) <= KMAX
+    p = Polygon()
+    p.k = len(xs)
+    for i in range(len(xs)):
+        p.x[i], p.y[i] = float(xs[i]), float(ys[i])
+    return p
+
+
+def _as_polygon(p) -> Polygon:
+    return p if isinstance(p, Polygon) else polygon(*p) if isinstance(p, tuple) else polygon(p)
+
+
+def place_polygon(poly, dx, dy, dt):
+    """robot placement: rot_trans_rectangle per vertex -> (x[k], y[k])"""
+    poly = _as_polygon(poly)
+    ox, oy = np.empty(poly.k, np.float32), np.empty(poly.k, np.float32)
+    lib().c2d_oracle_place_polygon(C.byref(poly), dx, dy, dt, _ptr(ox), _ptr(oy))
+    return ox, oy
+
+
+def sample_polygon(poly, sd, normals5):
+    poly = _as_polygon(poly)
+    n5 = _f32(normals5)
+    ox, oy = np.empty(poly.k, np.float32), np.empty(poly.k, np.float32)
+    lib().c2d_oracle_sample_polygon(C.byref(poly), C.byref(StdDev(*sd)), _ptr(n5), _ptr(ox), _ptr(oy))
+    return ox, oy
+
+
+def mc_poly_sampled(obstacle, sd, seed, scene_id, sample):
+    obstacle = _as_polygon(obstacle)
+    ox, oy = np.empty(obstacle.k, np.float32), np.empty(obstacle.k, np.float32)
+    lib().c2d_oracle_mc_poly_sampled(C.byref(obstacle), C.byref(StdDev(*sd)), seed, scene_id, sample, _ptr(ox), _ptr(oy))
+    return ox, oy
+
+
+def mc_poly_pair(robot, pos, robot_theta, obstacle, sd, seed, scene_id, sample_begin, n_samples) -> int:
+    r = int(lib().c2d_oracle_mc_poly_pair(C.byref(_as_polygon(robot)), C.byref(Position(*pos)), robot_theta, C.byref(_as_polygon(obstacle)),
+                                          C.byref(StdDev(*sd)), seed, scene_id, sample_begin, n_samples))
+    if r == 2 ** 64 - 1:
+        raise ValueError("polygon vertex count outside 1..KMAX")
+    return r
+
+
+def mc_poly_scenes(robot, poly_poses, std_devs, scenes, bins, acc, max_samples, seed, scene_id_base=0, schedule=(0, 0, 0)):
+    """robot: Polygon; poly_poses: POLY_POSE_DT[np]; std_devs: STD_DT[nv]; scenes: SCENE_DT[n].
+    -> hits u32[n], n_used u32[n], rows ROW_DT[n], total samples"""
+    poly_poses = np.ascontiguousarray(poly_poses, dtype=POLY_POSE_DT)
+    std_devs = np.ascontiguousarray(std_devs, dtype=STD_DT)
+    scenes = np.ascontiguousarray(scenes, dtype=SCENE_DT)
+    bins, acc = _f32(bins), _f32(acc)
+    assert len(acc) == len(bins) - 1
+    n = scenes.shape[0]
+    hits, used, rows = np.empty(n, np.uint32), np.empty(n, np.uint32), np.empty(n, ROW_DT)
+    robot = _as_polygon(robot)
+    total = lib().c2d_oracle_mc_poly_scenes(
+        C.byref(robot), C.c_void_p(poly_poses.ctypes.data), C.c_uint32(len(poly_poses)), C.c_void_p(std_devs.ctypes.data),
+        C.c_uint32(len(std_devs)), C.c_void_p(scenes.ctypes.data), C.c_size_t(n), _ptr(bins), _ptr(acc), C.c_uint32(len(bins)),
+        C.c_uint32(max_samples), C.c_uint64(seed), C.c_uint64(scene_id_base), C.c_uint32(schedule[0]), C.c_uint32(schedule[1]),
+        C.c_uint32(schedule[2]), C.c_void_p(hits.ctypes.data), C.c_void_p(used.ctypes.data), C.c_void_p(rows.ctypes.data))
+    return hits, used, rows, int(total)
 
 
 def mc_sampled_rect(pose, sd, seed, scene_id, sample):
