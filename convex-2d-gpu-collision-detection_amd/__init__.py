@@ -20,6 +20,9 @@ from .binding import (  # noqa: F401
     STD_DT,
     SCENE_DT,
     ROW_DT,
+    POLY_DT,
+    POLY_POSE_DT,
+    make_polygon,
     library_path,
     load_library,
 )

@@ -22,6 +22,11 @@ SCENE_DT = np.dtype([("x", "<f4"), ("y", "<f4"), ("var_idx", "<f4"), ("pose_idx"
 ROW_DT = np.dtype([("x", "<f4"), ("y", "<f4"), ("cp", "<f4"), ("var_idx", "<f4"), ("pose_idx", "<f4")])
 
 
+# polygon Monte-Carlo (include/c2d.h, "Monte-Carlo collision probability for convex polygons")
+POLY_DT = np.dtype([("k", "<u4"), ("x", "<f4", (KMAX,)), ("y", "<f4", (KMAX,))])       # c2d_polygon
+POLY_POSE_DT = np.dtype([("theta", "<f4"), ("obstacle", POLY_DT)])                       # c2d_poly_pose
+
+
 class C2DError(RuntimeError):
     def __init__(self, status: int, what: str, detail: str = ""):
         self.status = status
@@ -64,6 +69,36 @@ class _McScenesArgs(C.Structure):
         ("d_hits", C.c_void_p), ("d_n_used", C.c_void_p), ("d_rows", C.c_void_p),
         ("total_samples", C.POINTER(C.c_uint64)), ("iterations", C.POINTER(C.c_uint32)),
     ]
+
+
+class _Polygon(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("x", C.c_float * KMAX), ("y", C.c_float * KMAX)]
+
+
+class _McPolyScenesArgs(C.Structure):
+    _fields_ = [("base", _McScenesArgs), ("robot", C.POINTER(_Polygon)), ("d_poly_poses", C.c_void_p), ("num_poly_poses", C.c_uint32)]
+
+
+def make_polygon(xs, ys=None) -> _Polygon:
+    """A c2d_polygon from vertex coordinates (xs, ys), or from one POLY_DT record."""
+    if isinstance(xs, _Polygon):
+        return xs
+    if ys is None:
+        rec = xs
+        k = int(rec["k"])
+        p = _Polygon()
+        p.k = k  # (as given: the library validates it)
+        for i in range(KMAX):
+            p.x[i], p.y[i] = float(rec["x"][i]), float(rec["y"][i])
+        return p
+    xs, ys = np.asarray(xs, np.float32), np.asarray(ys, np.float32)
+    if not (len(xs) == len(ys) <= KMAX):
+        raise ValueError("a polygon has at most %d vertices" % KMAX)
+    p = _Polygon()
+    p.k = len(xs)
+    for i in range(len(xs)):
+        p.x[i], p.y[i] = float(xs[i]), float(ys[i])
+    return p
 
 
 def library_path() -> str:
@@ -114,6 +149,9 @@ _SIGNATURES = {
     "c2d_mc_pair": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.POINTER(_Position), C.POINTER(_Pose), C.POINTER(_StdDev),
                               C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
     "c2d_mc_scenes": (C.c_int, [C.c_void_p, C.POINTER(_McScenesArgs), C.c_void_p]),
+    "c2d_mc_poly_pair": (C.c_int, [C.c_void_p, C.POINTER(_Polygon), C.POINTER(_Position), C.c_float, C.POINTER(_Polygon), C.POINTER(_StdDev),
+                                   C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "c2d_mc_poly_scenes": (C.c_int, [C.c_void_p, C.POINTER(_McPolyScenesArgs), C.c_void_p]),
     "c2d_sample_scenes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_float,
                                     C.c_uint64, C.c_uint64, C.c_size_t, C.c_void_p, C.c_void_p]),
     "c2d_dist_unique_id": (C.c_int, [C.c_void_p]),
@@ -479,6 +517,31 @@ class Engine:
                           len(bins), max_samples, seed, scene_id_base, schedule[0], schedule[1], schedule[2],
                           _ptr_of(hits), _ptr_of(n_used), _ptr_of(rows), None, None)
         self._check(self.lib.c2d_mc_scenes(self.h, C.byref(a), C.c_void_p(stream)), "c2d_mc_scenes")
+
+    def mc_poly_pair(self, robot, pos, robot_theta, obstacle, std_dev, seed, scene_id, sample_begin, n_samples, hits, stream: int = 0):
+        """robot, obstacle: (xs, ys) tuples, POLY_DT records or make_polygon() results"""
+        r = make_polygon(*robot) if isinstance(robot, tuple) else make_polygon(robot)
+        o = make_polygon(*obstacle) if isinstance(obstacle, tuple) else make_polygon(obstacle)
+        self._check(self.lib.c2d_mc_poly_pair(self.h, C.byref(r), C.byref(_Position(*pos)), robot_theta, C.byref(o), C.byref(_StdDev(*std_dev)),
+                                              seed, scene_id, sample_begin, n_samples, _ptr_of(hits), C.c_void_p(stream)), "c2d_mc_poly_pair")
+
+    def mc_poly_scenes(self, robot, poly_poses, num_poly_poses, std_devs, num_std_devs, scenes, n_scenes, accuracy_bins, bin_accuracy, max_samples,
+                       seed, scene_id_base, hits, n_used, rows=None, stream: int = 0, schedule=(0, 0, 0), host_outputs: bool = True):
+        """c2d_mc_poly_scenes; with host_outputs=False the loop is only enqueued (no synchronisation) and None is returned"""
+        bins = np.ascontiguousarray(accuracy_bins, dtype=np.float32)
+        acc = np.ascontiguousarray(bin_accuracy, dtype=np.float32)
+        if len(acc) != len(bins) - 1:
+            raise ValueError("bin_accuracy must have len(accuracy_bins) - 1 entries")
+        total, iters = C.c_uint64(0), C.c_uint32(0)
+        base = _McScenesArgs(None, 0, _ptr_of(std_devs), num_std_devs, _ptr_of(scenes), n_scenes, 0.0, 0.0,
+                             bins.ctypes.data_as(C.POINTER(C.c_float)), acc.ctypes.data_as(C.POINTER(C.c_float)),
+                             len(bins), max_samples, seed, scene_id_base, schedule[0], schedule[1], schedule[2],
+                             _ptr_of(hits), _ptr_of(n_used), _ptr_of(rows),
+                             C.pointer(total) if host_outputs else None, C.pointer(iters) if host_outputs else None)
+        r = None if robot is None else (make_polygon(*robot) if isinstance(robot, tuple) else make_polygon(robot))
+        a = _McPolyScenesArgs(base, C.pointer(r) if r is not None else None, _ptr_of(poly_poses), num_poly_poses)
+        self._check(self.lib.c2d_mc_poly_scenes(self.h, C.byref(a), C.c_void_p(stream)), "c2d_mc_poly_scenes")
+        return (int(total.value), int(iters.value)) if host_outputs else None
 
     def sample_scenes(self, poses, num_poses, std_devs, num_std_devs, robot_w, robot_h, spread, seed, scene_id_base,
                       n_scenes, scenes, stream: int = 0):

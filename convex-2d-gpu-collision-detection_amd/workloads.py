@@ -125,3 +125,80 @@ def inject_non_finite(values: np.ndarray, seed: int, frac: float = 0.5, axis_ite
         sel = victims[rng.random(victims.size) < (1.0 if rep == 0 else 0.4)]
         flat[rng.integers(0, planes, sel.size), sel] = rng.choice(junk, sel.size)
     return out
+
+
+def convex_polygon(k: int, rng, a: float = 1.0, b: float = 1.0, rot: float = 0.0, clockwise: bool = False):
+    """k vertices at sorted random angles on an ellipse with half axes a, b about the origin, rotated by rot: float32 xs, ys"""
+    ang = np.sort(rng.uniform(0.0, 2.0 * np.pi, k))
+    if clockwise:
+        ang = ang[::-1]
+    x, y = a * np.cos(ang), b * np.sin(ang)
+    c, s = np.cos(rot), np.sin(rot)
+    return (c * x - s * y).astype(np.float32), (s * x + c * y).astype(np.float32)
+
+
+def rect_polygon(w: float, h: float):
+    """create_rect (utils.cu:119-130) as a 4-gon: the same floats in the same order"""
+    w, h = np.float32(w), np.float32(h)
+    two = np.float32(2)
+    return (np.array([-w / two, w / two, w / two, -w / two], np.float32), np.array([-h / two, -h / two, h / two, h / two], np.float32))
+
+
+def near_regular_polygon(k: int, rng, a: float, b: float, rot: float = 0.0):
+    """k vertices on an ellipse at angles 2 pi (i + jitter_i) / k, |jitter| < 0.3: a full-bodied convex polygon"""
+    ang = 2.0 * np.pi * (np.arange(k) + rng.uniform(-0.3, 0.3, k)) / k
+    x, y = a * np.cos(ang), b * np.sin(ang)
+    c, s = np.cos(rot), np.sin(rot)
+    return (c * x - s * y).astype(np.float32), (s * x + c * y).astype(np.float32)
+
+
+# The polygon counterpart of MC_PAIR_SCENE: a robot polygon about the size of the reference's robot (4.07 x 1.74), an obstacle
+# about the size of config 3's (2 x 1), the same pose noise; placed so that about half of the samples collide.
+def mc_poly_pair_scene(ka: int = 7, kb: int = 5, seed: int = 11, pos=(2.8, 1.0)):
+    rng = np.random.Generator(np.random.Philox(seed))
+    return {
+        "robot": near_regular_polygon(ka, rng, 4.07 / 2 * 1.15, 1.74 / 2 * 1.15),
+        "pos": pos, "theta": 0.6,
+        "obstacle": near_regular_polygon(kb, rng, 1.15, 0.6, rot=0.3),
+        "std_dev": (0.3, 0.3, 0.2, 0.0, 0.0),
+    }
+
+
+def random_poly_tables(num_poses: int, num_variances: int, seed: int = 7, kmin: int = 3, kmax: int = KMAX, shape_variance: bool = False):
+    """The polygon counterpart of random_tables: POLY_POSE_DT[num_poses] — robot rotation ~ U(0, 2 pi) and an obstacle polygon with
+    K ~ U{kmin..kmax} vertices on an ellipse with half axes ~ U(0.05, 2.5) (the reference's obstacle sizes 0.1 .. 5,
+    generate_dataset.cu:56-57) — and STD_DT[num_variances] as random_tables draws it (relative width / height deviations
+    ~ sqrt(U(0, 0.02)) when shape_variance)."""
+    from .binding import POLY_POSE_DT, STD_DT
+
+    rng = np.random.Generator(np.random.Philox(seed))
+    var = rng.uniform(0.0, 0.3, size=(num_variances, 5)).astype(np.float32)
+    var[:, 3:] = rng.uniform(0.0, 0.02, size=(num_variances, 2)) if shape_variance else 0.0
+    sd = np.sqrt(var).astype(np.float32)
+    poses = np.zeros(num_poses, POLY_POSE_DT)
+    poses["theta"] = rng.uniform(0.0, 2.0 * np.pi, num_poses)
+    ks = rng.integers(kmin, kmax + 1, num_poses)
+    for i in range(num_poses):
+        x, y = convex_polygon(int(ks[i]), rng, rng.uniform(0.05, 2.5), rng.uniform(0.05, 2.5), rng.uniform(0, 2 * np.pi), clockwise=bool(rng.integers(0, 2)))
+        poses["obstacle"]["k"][i] = ks[i]
+        poses["obstacle"]["x"][i, :ks[i]] = x
+        poses["obstacle"]["y"][i, :ks[i]] = y
+    return poses, sd.view(STD_DT).reshape(-1)
+
+
+def random_poly_scenes(n: int, poly_poses, std_devs, robot_radius: float, seed: int = 3, spread: float = 4.0):
+    """SCENE_DT[n] rows for a polygon dataset, in the spirit of generate_dataset.cu:207-219: table indices uniform, the robot on a
+    ring around the obstacle at about touching distance, shifted by a normal draw of the scene's position noise."""
+    from .binding import SCENE_DT
+
+    rng = np.random.Generator(np.random.Philox(seed))
+    rows = np.zeros(n, SCENE_DT)
+    pi_, vi = rng.integers(0, len(poly_poses), n), rng.integers(0, len(std_devs), n)
+    ob = poly_poses["obstacle"]
+    rad = np.sqrt(ob["x"] ** 2 + ob["y"] ** 2).max(axis=1)[pi_]
+    sdm = (std_devs["x"][vi] + std_devs["y"][vi]) / 2
+    dist = 0.7 * (rad + robot_radius) + sdm + rng.normal(0, 1, n) * sdm * spread / 4
+    th = rng.uniform(0, 2 * np.pi, n)
+    rows["x"], rows["y"] = dist * np.cos(th), dist * np.sin(th)
+    rows["var_idx"], rows["pose_idx"] = vi, pi_
+    return rows

@@ -190,6 +190,33 @@ def poly_collide_batch(vx, vy, k):
     return collide.astype(np.uint8)
 
 
+def place_polygon_given_cs(xs, ys, dx, dy, c, s):
+    """rot_trans_rectangle (utils.cu:136-141) applied to every vertex of a polygon, cos / sin supplied by the caller:
+    the robot placement of the polygon Monte-Carlo (ccp.cu:132-133)."""
+    xs, ys = np.asarray(xs, dtype=F32), np.asarray(ys, dtype=F32)
+    dx, dy, c, s = F32(dx), F32(dy), F32(c), F32(s)
+    return (c * xs - s * ys) + dx, (s * xs + c * ys) + dy
+
+
+def sample_polygon_given_cs(xs, ys, std_dev, normals5, c, s):
+    """sample_rectangle (utils.cu:144-157) for a polygon about the origin: the five normals in the reference's order
+    dx, dy, dtheta, dw, dh; dw, dh change the shape first — a rectangle's half extents grow by dw / 2, dh / 2
+    (utils.cu:152-155), a polygon's obstacle-frame coordinates are scaled by (1 + dw), (1 + dh), std_dev width / height
+    being relative — then the shape is rotated by dtheta (cos / sin supplied: the canonical sincos lives in the C oracle)
+    and moved by (dx, dy) (utils.cu:156).  Written against the reference source and include/c2d.h, not against
+    oracle/c2d_oracle.c."""
+    xs, ys = np.asarray(xs, dtype=F32), np.asarray(ys, dtype=F32)
+    sd = [F32(v) for v in std_dev]
+    n = [F32(v) for v in normals5]
+    with np.errstate(all="ignore"):
+        dx, dy = n[0] * sd[0], n[1] * sd[1]
+        dw, dh = n[3] * sd[3], n[4] * sd[4]
+        fx, fy = F32(1) + dw, F32(1) + dh
+        x, y = fx * xs, fy * ys
+        c, s = F32(c), F32(s)
+        return (c * x - s * y) + dx, (s * x + c * y) + dy
+
+
 def _main():
     """BASELINE config 1: the 1 000 fixed OBB pairs of tests/golden/sat_rect_1k.npz on the CPU,
     boolean collide output.  `python oracle/sat.py [--print]`"""

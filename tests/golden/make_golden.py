@@ -118,6 +118,39 @@ def main():
                         scene_seed=np.uint64(99), spread=np.float32(4.0))
     print("mc_scenes_64.npz: total samples", total, "n_used histogram", np.unique(used, return_counts=True))
 
+    # ---- MC over convex polygons: fixed scenes, exact hit counts (oracle/c2d_oracle.c "Monte-Carlo over convex polygons") -------------
+    rng = np.random.Generator(np.random.Philox(2024))
+    rec = {k: [] for k in ("ka", "kb", "rx", "ry", "ox", "oy", "pos", "theta", "std_dev", "seed", "scene", "begin", "n", "hits")}
+    specs = [(7, 5, wl.mc_poly_pair_scene()["pos"], (0.3, 0.3, 0.2, 0.0, 0.0)), (3, 3, (1.8, 0.4), (0.4, 0.2, 0.3, 0.1, 0.0)), (16, 16, (3.2, -1.0), (0.3, 0.3, 0.2, 0.05, 0.08)),
+             (4, 12, (-2.6, 1.4), (0.5, 0.5, 0.4, 0.0, 0.0)), (9, 2, (2.2, 0.3), (0.2, 0.6, 1.0, 0.0, 0.3)), (1, 6, (0.4, 0.2), (0.8, 0.8, 0.0, 0.2, 0.2)),
+             (5, 8, (6.5, 2.0), (0.4, 0.4, 0.2, 0.0, 0.0)), (12, 7, (9.0, -9.0), (0.5, 0.5, 0.5, 0.1, 0.1))]
+    for i, (ka, kb, pos, sd) in enumerate(specs):
+        scp = wl.mc_poly_pair_scene(ka, kb, seed=300 + i) if i else wl.mc_poly_pair_scene()
+        theta = 0.6 if i == 0 else float(rng.uniform(-3.2, 3.2))  # case 0: the bench scene of the polygon leg
+        begin, n = 1000 + 3 * i, 150_000
+        h = cpu.mc_poly_pair(scp["robot"], pos, theta, scp["obstacle"], sd, 1234, i, begin, n)
+        pad = lambda v: np.concatenate([v, np.zeros(wl.KMAX - len(v), np.float32)])  # noqa: E731
+        for key, val in (("ka", ka), ("kb", kb), ("rx", pad(scp["robot"][0])), ("ry", pad(scp["robot"][1])), ("ox", pad(scp["obstacle"][0])),
+                         ("oy", pad(scp["obstacle"][1])), ("pos", pos), ("theta", theta), ("std_dev", sd), ("seed", 1234), ("scene", i), ("begin", begin),
+                         ("n", n), ("hits", h)):
+            rec[key].append(val)
+    np.savez_compressed(os.path.join(HERE, "mc_poly_pair_cases.npz"), ka=np.array(rec["ka"], np.uint32), kb=np.array(rec["kb"], np.uint32),
+                        rx=np.array(rec["rx"], np.float32), ry=np.array(rec["ry"], np.float32), ox=np.array(rec["ox"], np.float32), oy=np.array(rec["oy"], np.float32),
+                        pos=np.array(rec["pos"], np.float32), theta=np.array(rec["theta"], np.float32), std_dev=np.array(rec["std_dev"], np.float32),
+                        seed=np.array(rec["seed"], np.uint64), scene=np.array(rec["scene"], np.uint64), begin=np.array(rec["begin"], np.uint64),
+                        n=np.array(rec["n"], np.uint64), hits=np.array(rec["hits"], np.uint64))
+    print("mc_poly_pair_cases.npz:", rec["hits"])
+
+    # ---- MC over convex polygons, adaptive: 48 scenes, max_samples 25 000 -------------------------------------------------------------
+    pposes, psd = wl.random_poly_tables(24, 24, seed=13, shape_variance=True)
+    scp = wl.mc_poly_pair_scene(9, 5, seed=14)
+    pscn = wl.random_poly_scenes(48, pposes, psd, 2.3, seed=15)
+    hits, used, rows, total = cpu.mc_poly_scenes(scp["robot"], pposes, psd, pscn, wl.DEFAULT_BINS, wl.DEFAULT_BIN_ACCURACY, 25000, 4321, 500)
+    np.savez_compressed(os.path.join(HERE, "mc_poly_scenes_48.npz"), robot_x=scp["robot"][0], robot_y=scp["robot"][1], poly_poses=pposes, std_devs=psd,
+                        scenes=pscn, hits=hits, n_used=used, rows=rows, total_samples=np.uint64(total), max_samples=np.uint32(25000), seed=np.uint64(4321),
+                        scene_id_base=np.uint64(500))
+    print("mc_poly_scenes_48.npz: total samples", total, "n_used histogram", np.unique(used, return_counts=True))
+
 
 if __name__ == "__main__":
     main()
