@@ -465,6 +465,45 @@ def main() -> None:
                               "frac": round(lane_ops / VALU_PEAK_TLANE, 4), "valu_instr_per_sample": c["valu_instr_per_sample"],
                               "instr_source": c.get("source")}
 
+    # ---- Monte-Carlo over convex polygons (README.md:3 "arbitrary convex 2D shapes"; include/c2d.h c2d_mc_poly_pair) -------------
+    mc_poly = None
+    if not args.no_mc:
+        psc = wl.mc_poly_pair_scene()  # 7-gon robot, pentagon obstacle, config 3's pose noise, p ~ 0.57
+        phits = torch.zeros(1, dtype=torch.int64, device=dev)
+        PS = args.mc_samples
+        p_robot, p_obst = pkg.make_polygon(*psc["robot"]), pkg.make_polygon(*psc["obstacle"])
+
+        def mc_poly_step():
+            eng.mc_poly_pair(p_robot, psc["pos"], psc["theta"], p_obst, psc["std_dev"], 1234, 0, rank * PS, PS, phits.data_ptr(), stream=sh)
+
+        prewarm(mc_poly_step)
+        torch.cuda.synchronize()
+        phits.zero_()
+        barrier()
+        torch.cuda.synchronize()
+        pm0 = time.perf_counter()
+        pe0, pe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        pe0.record(stream)
+        for _ in range(args.mc_reps):
+            mc_poly_step()
+        pe1.record(stream)
+        mc_poly_hits_one_step = int(phits.item()) // args.mc_reps if world == 1 else None
+        all_reduce_sum(phits)
+        torch.cuda.synchronize()
+        barrier()
+        pmel = shd.max_over_ranks(time.perf_counter() - pm0, dev)
+        mc_poly_ms = pe0.elapsed_time(pe1) / args.mc_reps
+        mc_poly = {"metric": "mc_poly_samples_per_s", "value": PS * world * args.mc_reps / pmel, "samples_per_gpu": PS, "reps": args.mc_reps,
+                   "kernel_ms": round(mc_poly_ms, 4), "probability": float(phits.item()) / (PS * world * args.mc_reps),
+                   "scene": "7-gon robot about 4.7 x 2.0 at (2.8, 1.0) th=0.6, pentagon obstacle about 2.3 x 1.2, sigma=(.3,.3,.2,0,0)",
+                   "bound": "valu", "note": "~0 HBM bytes per sample; one sample per lane, the interval test on all ka + kb true normals (DESIGN.md §5)"}
+        c = counts.get("mc_poly_pair.bench")
+        if c:
+            lane_ops = PS / (mc_poly_ms * 1e-3) * c["valu_instr_per_sample"] / 1e12
+            mc_poly["roofline"] = {"bound": "valu", "kernel": "mc_poly_pair_kernel", "achieved": round(lane_ops, 2), "peak": VALU_PEAK_TLANE,
+                                   "unit": "T VALU lane-instr/s per GPU", "frac": round(lane_ops / VALU_PEAK_TLANE, 4),
+                                   "valu_instr_per_sample": c["valu_instr_per_sample"], "instr_source": c.get("source")}
+
     # ---- config 4: adaptive Monte-Carlo over many scenes -------------------------------------
     scenes_leg, scenes_keep = None, None
     if args.scenes > 0:
@@ -750,6 +789,24 @@ def main() -> None:
             mc["cpu_baseline"] = {"value": done / cel, "unit": "samples/s", "cores": oracle.num_threads(), "kind": "port",
                                   "sample": f"first {done} samples of the same stream ({cel:.1f} s), OpenMP", "probability": h / done,
                                   "parity": mc["parity"]}
+        if mc_poly is not None:  # the polygon Monte-Carlo leg: all PS samples of one step, hit for hit, then the timed walk
+            done, h, h_at_s = 0, 0, None
+            c0 = time.perf_counter()
+            while True:
+                m = min(4_000_000, PS - done) if done < PS else 4_000_000
+                h += oracle.mc_poly_pair(psc["robot"], psc["pos"], psc["theta"], psc["obstacle"], psc["std_dev"], 1234, 0, done, m)
+                done += m
+                if done == PS:
+                    h_at_s = h
+                if done >= PS and time.perf_counter() - c0 >= budget:
+                    break
+            cel = time.perf_counter() - c0
+            mc_poly["parity"] = f"hits equal on {PS} of {PS} samples ({mc_poly_hits_one_step} hits)"
+            if h_at_s != mc_poly_hits_one_step:
+                raise SystemExit(f"PARITY FAILURE: polygon Monte-Carlo hit count over the first {PS} samples: GPU {mc_poly_hits_one_step}, CPU oracle {h_at_s}")
+            mc_poly["cpu_baseline"] = {"value": done / cel, "unit": "samples/s", "cores": oracle.num_threads(), "kind": "port",
+                                       "sample": f"first {done} samples of the same stream ({cel:.1f} s), OpenMP", "probability": h / done,
+                                       "parity": mc_poly["parity"]}
         if poly_keep is not None:  # config 5: every boolean of the 16-row batch
             hvx, hvy, hk, hout = poly_keep
             ref, ref_cnt = oracle.sat_poly_pairs(hvx, hvy, hk)
@@ -809,7 +866,7 @@ def main() -> None:
                        "parallelism": f"pairs sharded over {world} GPU(s), one process per GPU, no data-path collective, one sum of the hit count per leg",
                        "reduce": reduce_impl,
                        "ranks_in_reduce": (cdist.world_size if cdist is not None else (dist.get_world_size() if use_dist else 1))},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "mask_output": mask_leg, "pose_format": pose_leg, "mc": mc, "scenes": scenes_leg, "poly": poly_leg,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "mask_output": mask_leg, "pose_format": pose_leg, "mc": mc, "mc_poly": mc_poly, "scenes": scenes_leg, "poly": poly_leg,
             "device": eng.info()["name"],
         }
         sys.stdout.flush()

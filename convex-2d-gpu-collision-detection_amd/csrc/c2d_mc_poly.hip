@@ -14,6 +14,8 @@
 //   evaluation one sample per lane: the lane transforms the obstacle's vertices into registers (scale, rotate, move — the
 //              arithmetic of the oracle's sample_polygon, float for float) and runs the interval test of utils.cu:172-180 on
 //              the true normals of all ka + kb edges; robot data arrive as LDS broadcasts (every lane reads the same address).
+#include <type_traits>
+
 #include "c2d_internal.hpp"
 #include "c2d_math.hpp"
 #include "c2d_mc_core.hpp"
@@ -146,8 +148,8 @@ C2D_DEV PolyScene build_poly_scene(float rvx, float rvy, int ka, float px, float
 }
 
 // ---- full evaluation of one sample per lane: the sampled obstacle (the oracle's sample_polygon) and the interval test on all
-// ka + kb true normals.  CB = the obstacle's vertex slots held in registers (kb rounded up to 4, 8, 12, 16; the padding slots
-// are neutral).  NANS: the scene is not tame, so a projection may be a NaN and the comparison-based extremes of
+// ka + kb true normals.  CB = the obstacle's vertex slots held in registers (kb rounded up to an even number; a padding slot
+// is neutral).  NANS: the scene is not tame, so a projection may be a NaN and the comparison-based extremes of
 // thrust::minmax_element (utils.cu:176-177) must be followed: one unordered compare of the two first projections per axis
 // (first_projections_ordered, c2d_math.hpp).  Returns the lanes of `lanes` whose sample collides.
 template <int CB, bool NANS>
@@ -181,12 +183,13 @@ C2D_DEV unsigned long long poly_sample_collides(const PolyScene& sc, const PolyQ
         sep |= m;
     }
     if ((lanes & ~sep) == 0ull) return 0ull;  // every lane of the pass is separated: no other axis can change an answer
-    // ---- the obstacle's edge normals, four at a time: own interval from the registers, the robot's from LDS broadcasts
+    // ---- the obstacle's edge normals, four at a time (the last group of a class that is not a multiple of four: two): own
+    // interval from the registers, the robot's from LDS broadcasts
+    auto group = [&](auto g_const, auto j0_const) {
+        constexpr int G = decltype(g_const)::value, j0 = decltype(j0_const)::value;
+        float nx[G], ny[G], mn1[G], mx1[G], mn2[G], mx2[G], q0[G], r0[G];
 #pragma unroll
-    for (int j0 = 0; j0 < CB; j0 += 4) {
-        float nx[4], ny[4], mn1[4], mx1[4], mn2[4], mx2[4], q0[4], r0[4];
-#pragma unroll
-        for (int a = 0; a < 4; a++) {
+        for (int a = 0; a < G; a++) {
             const int j = j0 + a, j1 = (j + 1) % CB;
             nx[a] = -(oy[j1] - oy[j]);
             ny[a] = ox[j1] - ox[j];
@@ -196,7 +199,7 @@ C2D_DEV unsigned long long poly_sample_collides(const PolyScene& sc, const PolyQ
 #pragma unroll
         for (int k = 1; k < CB; k++) {
 #pragma unroll
-            for (int a = 0; a < 4; a++) {
+            for (int a = 0; a < G; a++) {
                 const float p = nx[a] * ox[k] + ny[a] * oy[k];
                 mn2[a] = __builtin_fminf(mn2[a], p);
                 mx2[a] = __builtin_fmaxf(mx2[a], p);
@@ -205,7 +208,7 @@ C2D_DEV unsigned long long poly_sample_collides(const PolyScene& sc, const PolyQ
         {
             const float2 v = q.rvert[0];
 #pragma unroll
-            for (int a = 0; a < 4; a++) {
+            for (int a = 0; a < G; a++) {
                 r0[a] = nx[a] * v.x + ny[a] * v.y;
                 mn1[a] = mx1[a] = r0[a];
             }
@@ -214,20 +217,25 @@ C2D_DEV unsigned long long poly_sample_collides(const PolyScene& sc, const PolyQ
         for (int k = 1; k < ka; k++) {
             const float2 v = q.rvert[k];
 #pragma unroll
-            for (int a = 0; a < 4; a++) {
+            for (int a = 0; a < G; a++) {
                 const float p = nx[a] * v.x + ny[a] * v.y;
                 mn1[a] = __builtin_fminf(mn1[a], p);
                 mx1[a] = __builtin_fmaxf(mx1[a], p);
             }
         }
 #pragma unroll
-        for (int a = 0; a < 4; a++) {
+        for (int a = 0; a < G; a++) {
             unsigned long long m = __builtin_amdgcn_ballot_w64(mx1[a] < mn2[a]) | __builtin_amdgcn_ballot_w64(mx2[a] < mn1[a]);
             if constexpr (NANS) m &= __builtin_amdgcn_ballot_w64(first_projections_ordered(r0[a], q0[a]));
             sep |= m;
         }
-        if ((lanes & ~sep) == 0ull) return 0ull;
-    }
+    };
+    using std::integral_constant;
+    if constexpr (CB >= 4) { group(integral_constant<int, 4>{}, integral_constant<int, 0>{}); if ((lanes & ~sep) == 0ull) return 0ull; }
+    if constexpr (CB >= 8) { group(integral_constant<int, 4>{}, integral_constant<int, 4>{}); if ((lanes & ~sep) == 0ull) return 0ull; }
+    if constexpr (CB >= 12) { group(integral_constant<int, 4>{}, integral_constant<int, 8>{}); if ((lanes & ~sep) == 0ull) return 0ull; }
+    if constexpr (CB >= 16) { group(integral_constant<int, 4>{}, integral_constant<int, 12>{}); if ((lanes & ~sep) == 0ull) return 0ull; }
+    if constexpr (CB % 4 == 2) group(integral_constant<int, 2>{}, integral_constant<int, CB - 2>{});
     return lanes & ~sep;
 }
 
@@ -235,11 +243,15 @@ template <bool NANS>
 C2D_DEV unsigned long long poly_sample_collides_any(const PolyScene& sc, const PolyQueue& q, float dx, float dy, float c, float s, float fx, float fy,
                                                     unsigned long long lanes)
 {
-    const int cls = (sc.kb + 3) >> 2;  // wave-uniform
+    const int cls = (sc.kb + 1) >> 1;  // wave-uniform: vertex slots in registers = kb rounded up to an even number
     switch (cls) {
-    case 1: return poly_sample_collides<4, NANS>(sc, q, dx, dy, c, s, fx, fy, lanes);
-    case 2: return poly_sample_collides<8, NANS>(sc, q, dx, dy, c, s, fx, fy, lanes);
-    case 3: return poly_sample_collides<12, NANS>(sc, q, dx, dy, c, s, fx, fy, lanes);
+    case 1: return poly_sample_collides<2, NANS>(sc, q, dx, dy, c, s, fx, fy, lanes);
+    case 2: return poly_sample_collides<4, NANS>(sc, q, dx, dy, c, s, fx, fy, lanes);
+    case 3: return poly_sample_collides<6, NANS>(sc, q, dx, dy, c, s, fx, fy, lanes);
+    case 4: return poly_sample_collides<8, NANS>(sc, q, dx, dy, c, s, fx, fy, lanes);
+    case 5: return poly_sample_collides<10, NANS>(sc, q, dx, dy, c, s, fx, fy, lanes);
+    case 6: return poly_sample_collides<12, NANS>(sc, q, dx, dy, c, s, fx, fy, lanes);
+    case 7: return poly_sample_collides<14, NANS>(sc, q, dx, dy, c, s, fx, fy, lanes);
     default: return poly_sample_collides<16, NANS>(sc, q, dx, dy, c, s, fx, fy, lanes);
     }
 }
