@@ -14,6 +14,8 @@
 // lanes of phase 2 are dealt by the bin's axis count (rows_a + rows_b lanes per pair, as many pairs side by side as
 // fit the wave), not by a compile-time power of two.
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -388,13 +390,14 @@ C2D_DEV uint32_t bin_class(int ka, int kb, int rows, int g)
 
 // Binning is a stable counting sort by class in three passes, so that every bin keeps its pairs in input order and the
 // result does not depend on scheduling:
-//   count  a block takes 1024 consecutive pairs; every wave ranks its lanes within their class (ballot per distinct class)
-//          and the block writes its 256 class counts;
-//   scan   one block per class turns the column of block counts into exclusive prefixes (+ the class total for the host);
-//   move   the same ranking again gives slot = prefix[block][class] + pairs of the class in earlier waves + rank in the
-//          wave; every lane copies its own pair: coalesced reads of the padded rows, 4-byte writes that neighbouring
-//          lanes / waves / blocks of a class put next to each other.
+//   count  a block takes a TILE of 4096 consecutive pairs and counts them per class in an LDS histogram (256 words, LDS
+//          atomics), writes the tile's 256 counts and adds them to the sums of its CHUNK of 32 tiles;
+//   scan   one block per chunk, one thread per class (coalesced rows): the chunk's base is the sum of the earlier chunks'
+//          sums, then the tile counts become exclusive prefixes; the last chunk also leaves the class totals for the host;
+//   move   below.
 constexpr int kBinBlock = 1024, kBinWaves = kBinBlock / 64;
+constexpr int kMoveTile = 4096, kMoveSub = kMoveTile / kBinBlock;
+constexpr int kScanChunk = 32;  // tiles per chunk of the scan
 
 // rank of the lane among the wave's lanes of its class (lanes with ok == false take no part); s_wc[class] gets the wave's count
 C2D_DEV uint32_t wave_class_rank(uint32_t c, bool ok, uint16_t* s_wc)
@@ -414,47 +417,44 @@ C2D_DEV uint32_t wave_class_rank(uint32_t c, bool ok, uint16_t* s_wc)
 }
 
 __global__ __launch_bounds__(kBinBlock) void poly_bin_count_kernel(const uint8_t* __restrict__ k, size_t n, int rows, int g,
-                                                                    uint32_t* __restrict__ block_hist, uint32_t* __restrict__ n_bad)
+                                                                    uint32_t* __restrict__ tile_hist, uint32_t* __restrict__ chunk_sums,
+                                                                    uint32_t* __restrict__ n_bad)
 {
-    __shared__ uint16_t s_wc[kBinWaves][256];
-    for (int i = threadIdx.x; i < kBinWaves * 256; i += kBinBlock) (&s_wc[0][0])[i] = 0;
+    __shared__ uint32_t s_h[256];
+    if (threadIdx.x < 256) s_h[threadIdx.x] = 0;
     __syncthreads();
-    const size_t i = (size_t)blockIdx.x * kBinBlock + threadIdx.x;
-    uint32_t c = 0xffffffffu;
-    if (i < n) c = bin_class(k[i], k[n + i], rows, g);
-    const bool ok = c != 0xffffffffu;
-    if (__ballot(i < n && !ok) != 0 && (threadIdx.x & 63) == 0) atomicAdd(n_bad, 1u);
-    (void)wave_class_rank(c, ok, s_wc[threadIdx.x >> 6]);
+    const size_t tile0 = (size_t)blockIdx.x * kMoveTile;
+    bool bad = false;
+#pragma unroll
+    for (int sub = 0; sub < kMoveSub; sub++) {
+        const size_t i = tile0 + (size_t)sub * kBinBlock + threadIdx.x;
+        if (i < n) {
+            const uint32_t c = bin_class(k[i], k[n + i], rows, g);
+            if (c != 0xffffffffu) atomicAdd(&s_h[c], 1u);
+            else bad = true;
+        }
+    }
+    if (__ballot(bad) != 0 && (threadIdx.x & 63) == 0) atomicAdd(n_bad, 1u);
     __syncthreads();
     if (threadIdx.x < 256) {
-        uint32_t t = 0;
-#pragma unroll
-        for (int w = 0; w < kBinWaves; w++) t += s_wc[w][threadIdx.x];
-        block_hist[(size_t)blockIdx.x * 256 + threadIdx.x] = t;
+        const uint32_t v = s_h[threadIdx.x];
+        tile_hist[(size_t)blockIdx.x * 256 + threadIdx.x] = v;
+        if (v) atomicAdd(&chunk_sums[(size_t)(blockIdx.x / kScanChunk) * 256 + threadIdx.x], v);
     }
 }
 
-// exclusive prefix over the blocks, one class per block; totals[c] = pairs of the class
-__global__ __launch_bounds__(256) void poly_bin_scan_kernel(uint32_t* __restrict__ block_hist, uint32_t n_blocks, uint32_t* __restrict__ totals)
+// tile counts -> exclusive prefixes over the tiles, per class; totals[c] = pairs of the class
+__global__ __launch_bounds__(256) void poly_bin_scan_kernel(uint32_t* __restrict__ tile_hist, uint32_t n_tiles, const uint32_t* __restrict__ chunk_sums,
+                                                             uint32_t* __restrict__ totals)
 {
-    __shared__ uint32_t s_part[256];
-    const uint32_t c = blockIdx.x, t = threadIdx.x;
-    const uint32_t per = (n_blocks + 255) / 256;
-    const uint32_t b0 = t * per, b1 = (b0 + per) < n_blocks ? (b0 + per) : n_blocks;
-    uint32_t sum = 0;
-    for (uint32_t b = b0; b < b1; b++) sum += block_hist[(size_t)b * 256 + c];
-    s_part[t] = sum;
-    __syncthreads();
-    if (t == 0) {
-        uint32_t run = 0;
-        for (int i = 0; i < 256; i++) { const uint32_t v = s_part[i]; s_part[i] = run; run += v; }
-        totals[c] = run;
-    }
-    __syncthreads();
-    uint32_t run = s_part[t];
-    for (uint32_t b = b0; b < b1; b++) {
-        const uint32_t v = block_hist[(size_t)b * 256 + c];
-        block_hist[(size_t)b * 256 + c] = run;
+    const uint32_t c = threadIdx.x, chunk = blockIdx.x;
+    uint32_t run = 0;
+    for (uint32_t q = 0; q < chunk; q++) run += chunk_sums[(size_t)q * 256 + c];
+    if (chunk == gridDim.x - 1) totals[c] = run + chunk_sums[(size_t)chunk * 256 + c];
+    const uint32_t t0 = chunk * kScanChunk, t1 = (t0 + kScanChunk) < n_tiles ? (t0 + kScanChunk) : n_tiles;
+    for (uint32_t t = t0; t < t1; t++) {
+        const uint32_t v = tile_hist[(size_t)t * 256 + c];
+        tile_hist[(size_t)t * 256 + c] = run;
         run += v;
     }
 }
@@ -468,24 +468,36 @@ struct BinMoveArgs {
     const BinDesc* table;          // one entry per bin, polygons as in the INPUT (not the test kernel's swapped view)
     const uint16_t* class_to_bin;  // [256], 0xffff = empty class
     const uint32_t* pair_base;     // [bins]: first position of the bin in the concatenated order
-    const uint32_t* block_prefix;  // [blocks of 1024 pairs][256] from the scan
+    const uint32_t* tile_prefix;   // [tiles of 4096 pairs][256] from the scan
     const uint32_t* totals;        // [256] pairs per class
-    uint32_t n_blocks;             // blocks of 1024 pairs
+    uint32_t n_tiles;
+    uint32_t tiles_per_xcd;        // ceil(n_tiles / 8): block b takes tile (b % 8) * tiles_per_xcd + b / 8
     uint32_t* index;               // [n] out: position of input pair i; 0xffffffff = bad counts
+    float* base;                   // the block every plane of every bin lives in: a plane position is an element offset from here
 };
 
-// The move: a block owns a TILE of 4096 consecutive pairs (four of the count pass's blocks).  Lanes that write one pair each
-// scatter 4-byte stores over as many cache lines as there are classes in a wave (196 bins: 7.5 ms per 1e7 pairs), so the tile
-// is first sorted by destination: every pair gets its slot (prefix of its 1024-block and class + pairs of the class in earlier
-// waves + rank in its wave, as before), the tile's pairs are ordered by (class, slot) in LDS, and then every vertex row of
-// every plane passes through an LDS stage — read from the padded batch as it lies (coalesced), written in destination order,
-// where neighbouring lanes hold neighbouring slots of one class.
-constexpr int kMoveTile = 4096, kMoveSub = kMoveTile / kBinBlock;
-
-__global__ __launch_bounds__(kBinBlock) void poly_bin_move_kernel(BinMoveArgs A)
+// The move: a block owns a TILE of 4096 consecutive pairs.  Lanes that write one pair each scatter 4-byte stores over as many
+// cache lines as there are classes in a wave (196 bins: 7.5 ms per 1e7 pairs), so the tile is first sorted by destination:
+// every pair gets its slot (prefix of its tile and class + pairs of the class earlier in the tile + rank in its wave), the tile's
+// pairs are ordered by (class, slot) in LDS, and then every vertex row of every plane passes through an LDS stage — read from the
+// padded batch as it lies (coalesced), written in destination order, where neighbouring lanes hold neighbouring slots of one class.
+//
+// Round 4 (the form of round 3 moved 4.14 GB in 1.355 ms = 0.38 of the HBM peak, profiles/r03h_*):
+//  * a thread keeps everything about its four destination positions in REGISTERS (source index in the tile, row counts, stride,
+//    running plane pointers): a row costs it two LDS reads and two stores per position instead of nine LDS look-ups;
+//  * the next row's loads are issued BEFORE the current row is scattered, into registers: with one stage and two barriers per
+//    row the loads used to start only after the scatter had drained, and the bytes in flight per CU (two blocks x 32 KB, half of
+//    the time) covered about half of what the memory latency needs at full rate;
+//  * consecutive tiles go to the SAME XCD (block b of a launch runs on XCD b % 8): the run a tile contributes to a bin's row is
+//    about 21 floats and ends inside a cache line that the NEXT tile continues — written from the same L2 the two partial lines
+//    can merge before they leave for HBM.
+//  * plane positions are element offsets from the bins' block in 32 bits (Off = uint32_t; a block of 16 GiB or more takes the
+//    64-bit instance): at 16 waves per block the kernel must stay within 64 registers for two blocks to share a CU.
+template <typename Off>
+__global__ __launch_bounds__(kBinBlock, 2 * kBinWaves / 4) void poly_bin_move_kernel(BinMoveArgs A)
 {
     __shared__ float s_stage[2][kMoveTile];       // one vertex row of the tile, x and y
-    // per-wave class counts of the 1024-block in hand: only needed while the slots are computed, so they live in the stage
+    // per-wave class counts of the 1024 pairs in hand: only needed while the slots are computed, so they live in the stage
     uint16_t (*s_wc)[256] = reinterpret_cast<uint16_t (*)[256]>(&s_stage[0][0]);
     static_assert(sizeof(uint16_t) * kBinWaves * 256 <= sizeof(float) * kMoveTile, "s_wc fits the stage");
     __shared__ uint32_t s_slot[kMoveTile];        // slot of local pair li within its bin
@@ -493,12 +505,14 @@ __global__ __launch_bounds__(kBinBlock) void poly_bin_move_kernel(BinMoveArgs A)
     __shared__ uint16_t s_sorted[kMoveTile];      // local pair at position sp of the tile's (class, slot) order
     __shared__ uint32_t s_cbase[257];             // first position of class c in that order; [256] = valid pairs of the tile
     __shared__ uint32_t s_first[256];             // slot of the tile's first pair of class c
-    __shared__ float* s_plane[4][256];            // ax, ay, bx, by of the class's bin
+    __shared__ uint32_t s_run[256];               // pairs of class c in the tile's earlier sub-blocks
+    __shared__ Off s_plane[4][256];               // ax, ay, bx, by of the class's bin, as element offsets from A.base
     __shared__ uint32_t s_stride[256];
     __shared__ uint8_t s_rows[2][256];
     const uint32_t t = threadIdx.x, wave = t >> 6;
-    const uint32_t blk0 = blockIdx.x * kMoveSub;  // first 1024-block of the tile
-    const size_t tile0 = (size_t)blockIdx.x * kMoveTile;
+    const uint32_t tile = (blockIdx.x & 7u) * A.tiles_per_xcd + (blockIdx.x >> 3);
+    if (tile >= A.n_tiles) return;  // (block-uniform)
+    const size_t tile0 = (size_t)tile * kMoveTile;
     // ---- per-class tables of this tile
     if (t < 256) {
         const uint32_t c = t;
@@ -506,18 +520,18 @@ __global__ __launch_bounds__(kBinBlock) void poly_bin_move_kernel(BinMoveArgs A)
         uint32_t cnt = 0, first = 0;
         if (bin != 0xffffu) {
             const BinDesc D = A.table[bin];
-            s_plane[0][c] = const_cast<float*>(D.ax); s_plane[1][c] = const_cast<float*>(D.ay);
-            s_plane[2][c] = const_cast<float*>(D.bx); s_plane[3][c] = const_cast<float*>(D.by);
+            s_plane[0][c] = (Off)(D.ax - A.base); s_plane[1][c] = (Off)(D.ay - A.base);
+            s_plane[2][c] = (Off)(D.bx - A.base); s_plane[3][c] = (Off)(D.by - A.base);
             s_stride[c] = D.stride;
             s_rows[0][c] = (uint8_t)D.rows_a; s_rows[1][c] = (uint8_t)D.rows_b;
-            first = A.block_prefix[(size_t)blk0 * 256 + c];
-            const uint32_t next_blk = blk0 + kMoveSub;
-            const uint32_t end = next_blk < A.n_blocks ? A.block_prefix[(size_t)next_blk * 256 + c] : A.totals[c];
+            first = A.tile_prefix[(size_t)tile * 256 + c];
+            const uint32_t end = tile + 1 < A.n_tiles ? A.tile_prefix[(size_t)(tile + 1) * 256 + c] : A.totals[c];
             cnt = end - first;
         } else {
             s_rows[0][c] = s_rows[1][c] = 0;
         }
         s_first[c] = first;
+        s_run[c] = 0;
         s_cbase[c + 1] = cnt;  // counts for now
     }
     for (int i = t; i < kBinWaves * 256; i += kBinBlock) (&s_wc[0][0])[i] = 0;
@@ -546,9 +560,9 @@ __global__ __launch_bounds__(kBinBlock) void poly_bin_move_kernel(BinMoveArgs A)
         if (in) {
             uint32_t pos = 0xffffffffu;
             if (ok) {
-                uint32_t before = 0;  // pairs of the class in earlier waves of this 1024-block
+                uint32_t before = s_run[c];  // pairs of the class in earlier sub-blocks, then in earlier waves of this one
                 for (uint32_t w = 0; w < wave; w++) before += s_wc[w][c];
-                const uint32_t slot = A.block_prefix[(size_t)(blk0 + sub) * 256 + c] + before + rank;
+                const uint32_t slot = s_first[c] + before + rank;
                 s_slot[li] = slot;
                 s_sorted[s_cbase[c] + (slot - s_first[c])] = (uint16_t)li;
                 const uint32_t bin = A.class_to_bin[c];
@@ -562,28 +576,70 @@ __global__ __launch_bounds__(kBinBlock) void poly_bin_move_kernel(BinMoveArgs A)
             A.index[i] = pos;
         }
         __syncthreads();
+        if (t < 256) {
+            uint32_t add = 0;
+#pragma unroll
+            for (int w = 0; w < kBinWaves; w++) add += s_wc[w][t];
+            s_run[t] += add;
+        }
+        __syncthreads();
         for (int i2 = t; i2 < kBinWaves * 256; i2 += kBinBlock) (&s_wc[0][0])[i2] = 0;
         __syncthreads();
     }
     const uint32_t n_valid = s_cbase[256];
     const uint32_t here = (uint32_t)((A.n - tile0) < (size_t)kMoveTile ? (A.n - tile0) : (size_t)kMoveTile);
-    // ---- every vertex row of every plane through the stage
+    // ---- this thread's four destination positions, in registers
+    uint32_t d_li[kMoveSub], d_stride[kMoveSub], d_rows[kMoveSub];
+    Off d_x[2][kMoveSub], d_y[2][kMoveSub];
+#pragma unroll
+    for (int j = 0; j < kMoveSub; j++) {
+        const uint32_t sp = (uint32_t)j * kBinBlock + t;
+        d_li[j] = 0; d_stride[j] = 0; d_rows[j] = 0;  // rows 0 / 0: nothing to store
+        d_x[0][j] = d_y[0][j] = d_x[1][j] = d_y[1][j] = 0;
+        if (sp < n_valid) {
+            const uint32_t li = s_sorted[sp];
+            const uint32_t c = s_cls[li];
+            const uint32_t slot = s_slot[li];
+            d_li[j] = li;
+            d_stride[j] = s_stride[c];
+            d_rows[j] = (uint32_t)s_rows[0][c] | ((uint32_t)s_rows[1][c] << 8);
+            d_x[0][j] = s_plane[0][c] + slot; d_y[0][j] = s_plane[1][c] + slot;
+            d_x[1][j] = s_plane[2][c] + slot; d_y[1][j] = s_plane[3][c] + slot;
+        }
+    }
+    // ---- every vertex row of every plane through the stage; the next row is on its way while this one is scattered
+    float nx_[kMoveSub], ny_[kMoveSub];
+    auto fetch = [&](int poly, int r) {
+        const size_t row = ((size_t)poly * A.rows + r) * A.n + tile0;
+#pragma unroll
+        for (int e = 0; e < kMoveSub; e++) {
+            const uint32_t li = (uint32_t)e * kBinBlock + t;
+            nx_[e] = li < here ? __builtin_nontemporal_load(A.vx + row + li) : 0.0f;
+            ny_[e] = li < here ? __builtin_nontemporal_load(A.vy + row + li) : 0.0f;
+        }
+    };
+    fetch(0, 0);
+#pragma unroll
     for (int poly = 0; poly < 2; poly++) {
+#pragma nounroll
         for (int r = 0; r < A.rows; r++) {
-            const size_t row = ((size_t)poly * A.rows + r) * A.n + tile0;
-            for (uint32_t e = t; e < here; e += kBinBlock) {
-                s_stage[0][e] = A.vx[row + e];
-                s_stage[1][e] = A.vy[row + e];
+#pragma unroll
+            for (int e = 0; e < kMoveSub; e++) {
+                s_stage[0][e * kBinBlock + t] = nx_[e];
+                s_stage[1][e * kBinBlock + t] = ny_[e];
             }
             __syncthreads();
-            for (uint32_t sp = t; sp < n_valid; sp += kBinBlock) {
-                const uint32_t li = s_sorted[sp];
-                const uint32_t c = s_cls[li];
-                if (r < (int)s_rows[poly][c]) {
-                    const size_t at = (size_t)r * s_stride[c] + s_slot[li];
-                    s_plane[poly * 2][c][at] = s_stage[0][li];
-                    s_plane[poly * 2 + 1][c][at] = s_stage[1][li];
+            if (r + 1 < A.rows) fetch(poly, r + 1);
+            else if (poly == 0) fetch(1, 0);
+#pragma unroll
+            for (int j = 0; j < kMoveSub; j++) {
+                const uint32_t rows_here = (d_rows[j] >> (8 * poly)) & 0xffu;
+                if ((uint32_t)r < rows_here) {
+                    A.base[d_x[poly][j]] = s_stage[0][d_li[j]];
+                    A.base[d_y[poly][j]] = s_stage[1][d_li[j]];
                 }
+                d_x[poly][j] += d_stride[j];
+                d_y[poly][j] += d_stride[j];
             }
             __syncthreads();
         }
@@ -751,6 +807,16 @@ int c2d_sat_poly_pairs_binned(c2d_ctx* ctx, const c2d_poly_bins* bins, unsigned 
 int c2d_poly_bins_from_padded(c2d_ctx* ctx, const float* d_vx, const float* d_vy, const uint8_t* d_k, size_t n, int rows, int granularity,
                               c2d_poly_bins** out, c2d_stream stream)
 {
+    // developer aid: C2D_TRACE_BINS=1 prints the wall time of each phase to stderr (synchronising after each: not for timing the whole)
+    static const bool trace = getenv("C2D_TRACE_BINS") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[c2d bins] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(now - t_last).count());
+        t_last = std::chrono::steady_clock::now();
+    };
     if (!ctx || !out) return C2D_ERR_INVALID_ARG;
     *out = nullptr;
     if (rows < 1 || rows > C2D_POLY_KMAX) return fail_arg(ctx, "c2d_poly_bins_from_padded: rows must be 1..C2D_POLY_KMAX");
@@ -770,21 +836,24 @@ int c2d_poly_bins_from_padded(c2d_ctx* ctx, const float* d_vx, const float* d_vy
         hipError_t e__ = (call);                                                                 \
         if (e__ != hipSuccess) return fail(c2d::fail_hip(ctx, e__, #call, __FILE__, __LINE__));  \
     } while (0)
-    // ---- 1. pairs per (block of 1024, class), prefixes over the blocks, class totals
-    const size_t n_blocks = (n + kBinBlock - 1) / kBinBlock;
-    uint32_t* d_hist = nullptr;   // [n_blocks][256] counts -> prefixes, then [256] totals + 1 word of bad-count waves
-    C2D_BIN_HIP(hipMalloc(&d_hist, (n_blocks * 256 + 257) * sizeof(uint32_t)));
-    uint32_t* d_totals = d_hist + n_blocks * 256;
+    // ---- 1. pairs per (tile of 4096, class), prefixes over the tiles, class totals
+    const size_t n_tiles = (n + kMoveTile - 1) / kMoveTile;
+    const size_t n_chunks = (n_tiles + kScanChunk - 1) / kScanChunk;
+    uint32_t* d_hist = nullptr;   // [n_tiles][256] counts -> prefixes | [256] totals + 1 word of bad-count waves | [n_chunks][256] chunk sums
+    C2D_BIN_HIP(hipMalloc(&d_hist, (n_tiles * 256 + 257 + n_chunks * 256) * sizeof(uint32_t)));
+    uint32_t* d_totals = d_hist + n_tiles * 256;
+    uint32_t* d_chunk_sums = d_totals + 257;
     uint32_t hist[257];
-    hipError_t e = hipMemsetAsync(d_totals, 0, 257 * sizeof(uint32_t), s);
+    hipError_t e = hipMemsetAsync(d_totals, 0, (257 + n_chunks * 256) * sizeof(uint32_t), s);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(poly_bin_count_kernel, dim3((unsigned)n_blocks), dim3(kBinBlock), 0, s, d_k, n, rows, granularity, d_hist, d_totals + 256);
-        hipLaunchKernelGGL(poly_bin_scan_kernel, dim3(256), dim3(256), 0, s, d_hist, (uint32_t)n_blocks, d_totals);
+        hipLaunchKernelGGL(poly_bin_count_kernel, dim3((unsigned)n_tiles), dim3(kBinBlock), 0, s, d_k, n, rows, granularity, d_hist, d_chunk_sums, d_totals + 256);
+        hipLaunchKernelGGL(poly_bin_scan_kernel, dim3((unsigned)n_chunks), dim3(256), 0, s, d_hist, (uint32_t)n_tiles, d_chunk_sums, d_totals);
         e = hipMemcpyAsync(hist, d_totals, sizeof hist, hipMemcpyDeviceToHost, s);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) { (void)hipFree(d_hist); return fail(c2d::fail_hip(ctx, e, "class count", __FILE__, __LINE__)); }
     struct HistGuard { uint32_t* p; ~HistGuard() { (void)hipFree(p); } } hist_guard{d_hist};
+    lap("count + scan + read-back");
     B->had_bad_counts = hist[256] != 0;
     // ---- 2. layout of the block: per bin ax, ay, bx, by (stride = n rounded up to 64 elements, every plane 256-byte
     // aligned), counts (only when a bin can hold different sizes); then every bin's results back to back; then the index
@@ -830,7 +899,9 @@ int c2d_poly_bins_from_padded(c2d_ctx* ctx, const float* d_vx, const float* d_vy
     bytes = off_base + (n_bins + 1) * sizeof(uint32_t);
     const size_t off_c2b = align_up(bytes, 256);
     bytes = off_c2b + 256 * sizeof(uint16_t);
+    lap("host layout");
     hipError_t me = hipMalloc(&B->d_block, bytes);
+    lap("hipMalloc of the block");
     if (me == hipErrorOutOfMemory) { ctx->last_error = "c2d_poly_bins_from_padded: out of device memory"; return fail(C2D_ERR_NOMEM); }
     if (me != hipSuccess) return fail(c2d::fail_hip(ctx, me, "hipMalloc", __FILE__, __LINE__));
     char* base = static_cast<char*>(B->d_block);
@@ -850,6 +921,7 @@ int c2d_poly_bins_from_padded(c2d_ctx* ctx, const float* d_vx, const float* d_vy
     }
     int st = upload_table(ctx, B);
     if (st != C2D_OK) return fail(st);
+    lap("launch table upload");
     // the move kernel's view of the bins: polygon A = the input's polygon A
     std::vector<BinDesc> plain(n_bins);
     for (size_t b = 0; b < n_bins; b++) {
@@ -871,12 +943,17 @@ int c2d_poly_bins_from_padded(c2d_ctx* ctx, const float* d_vx, const float* d_vy
     A.table = d_plain;
     A.class_to_bin = reinterpret_cast<const uint16_t*>(base + off_c2b);
     A.pair_base = reinterpret_cast<const uint32_t*>(base + off_base);
-    A.block_prefix = d_hist;
+    A.tile_prefix = d_hist;
     A.totals = d_totals;
-    A.n_blocks = (uint32_t)n_blocks;
+    A.n_tiles = (uint32_t)n_tiles;
+    A.tiles_per_xcd = (uint32_t)((n_tiles + 7) / 8);
     A.index = B->d_index;
-    hipLaunchKernelGGL(poly_bin_move_kernel, dim3((unsigned)((n + kMoveTile - 1) / kMoveTile)), dim3(kBinBlock), 0, s, A);  // (n < 2^32)
+    lap("small copies + memset");
+    A.base = reinterpret_cast<float*>(base);
+    if (bytes < (16ull << 30)) hipLaunchKernelGGL(poly_bin_move_kernel<uint32_t>, dim3(A.tiles_per_xcd * 8u), dim3(kBinBlock), 0, s, A);  // (n < 2^32)
+    else hipLaunchKernelGGL(poly_bin_move_kernel<uint64_t>, dim3(A.tiles_per_xcd * 8u), dim3(kBinBlock), 0, s, A);
     C2D_BIN_HIP(hipStreamSynchronize(s));  // (the host vectors above must outlive their copies)
+    lap("move kernel");
 #undef C2D_BIN_HIP
     if (B->had_bad_counts) {
         release(B);
