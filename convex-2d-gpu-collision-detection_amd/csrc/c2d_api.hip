@@ -76,6 +76,7 @@ int c2d_ctx_destroy(c2d_ctx* ctx)
     if (ctx->d_count_words) (void)hipFree(ctx->d_count_words);
     if (ctx->d_count_words2) (void)hipFree(ctx->d_count_words2);
     if (ctx->d_bins) (void)hipFree(ctx->d_bins);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->h_async_err) (void)hipHostFree(ctx->h_async_err);
     delete ctx;

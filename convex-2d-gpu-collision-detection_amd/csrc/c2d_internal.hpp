@@ -19,6 +19,8 @@ struct c2d_ctx {
     unsigned long long* d_count_words = nullptr;  // 256 x 128 B arrival/sum words of the SAT count (self-clearing)
     unsigned long long* d_count_words2 = nullptr; // two-level form for the polygon kernels (c2d_count.hpp), self-clearing
     float* d_bins = nullptr;                   // accuracy_bins | bin_accuracy (<= 32 floats)
+    void* d_scratch = nullptr;                 // grown on demand, kept: the binning pass's histograms and tables (c2d_poly_bins_from_padded)
+    size_t scratch_bytes = 0;
     uint32_t* h_pinned = nullptr;              // pinned host word for count read-back
     // Deferred argument errors found by kernels (e.g. a polygon vertex count outside 1..KMAX): a pinned,
     // device-mapped word that kernels OR into with system scope; c2d_stream_synchronize /

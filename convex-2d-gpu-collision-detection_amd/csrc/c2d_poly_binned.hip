@@ -17,6 +17,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "c2d_internal.hpp"
@@ -390,13 +391,16 @@ C2D_DEV uint32_t bin_class(int ka, int kb, int rows, int g)
 
 // Binning is a stable counting sort by class in three passes, so that every bin keeps its pairs in input order and the
 // result does not depend on scheduling:
-//   count  a block takes a TILE of 4096 consecutive pairs and counts them per class in an LDS histogram (256 words, LDS
+//   count  a block takes a TILE of 8192 consecutive pairs (kMoveTile) and counts them per class in an LDS histogram (256 words, LDS
 //          atomics), writes the tile's 256 counts and adds them to the sums of its CHUNK of 32 tiles;
 //   scan   one block per chunk, one thread per class (coalesced rows): the chunk's base is the sum of the earlier chunks'
 //          sums, then the tile counts become exclusive prefixes; the last chunk also leaves the class totals for the host;
 //   move   below.
 constexpr int kBinBlock = 1024, kBinWaves = kBinBlock / 64;
-constexpr int kMoveTile = 4096, kMoveSub = kMoveTile / kBinBlock;
+#ifndef C2D_MOVE_TILE
+#define C2D_MOVE_TILE 8192
+#endif
+constexpr int kMoveTile = C2D_MOVE_TILE, kMoveSub = kMoveTile / kBinBlock;
 constexpr int kScanChunk = 32;  // tiles per chunk of the scan
 
 // rank of the lane among the wave's lanes of its class (lanes with ok == false take no part); s_wc[class] gets the wave's count
@@ -468,7 +472,7 @@ struct BinMoveArgs {
     const BinDesc* table;          // one entry per bin, polygons as in the INPUT (not the test kernel's swapped view)
     const uint16_t* class_to_bin;  // [256], 0xffff = empty class
     const uint32_t* pair_base;     // [bins]: first position of the bin in the concatenated order
-    const uint32_t* tile_prefix;   // [tiles of 4096 pairs][256] from the scan
+    const uint32_t* tile_prefix;   // [tiles of kMoveTile pairs][256] from the scan
     const uint32_t* totals;        // [256] pairs per class
     uint32_t n_tiles;
     uint32_t tiles_per_xcd;        // ceil(n_tiles / 8): block b takes tile (b % 8) * tiles_per_xcd + b / 8
@@ -476,40 +480,74 @@ struct BinMoveArgs {
     float* base;                   // the block every plane of every bin lives in: a plane position is an element offset from here
 };
 
-// The move: a block owns a TILE of 4096 consecutive pairs.  Lanes that write one pair each scatter 4-byte stores over as many
+// The move: a block owns a TILE of 8192 consecutive pairs (kMoveTile).  Lanes that write one pair each scatter 4-byte stores over as many
 // cache lines as there are classes in a wave (196 bins: 7.5 ms per 1e7 pairs), so the tile is first sorted by destination:
 // every pair gets its slot (prefix of its tile and class + pairs of the class earlier in the tile + rank in its wave), the tile's
 // pairs are ordered by (class, slot) in LDS, and then every vertex row of every plane passes through an LDS stage — read from the
 // padded batch as it lies (coalesced), written in destination order, where neighbouring lanes hold neighbouring slots of one class.
 //
-// Round 4 (the form of round 3 moved 4.14 GB in 1.355 ms = 0.38 of the HBM peak, profiles/r03h_*):
-//  * a thread keeps everything about its four destination positions in REGISTERS (source index in the tile, row counts, stride,
-//    running plane pointers): a row costs it two LDS reads and two stores per position instead of nine LDS look-ups;
-//  * the next row's loads are issued BEFORE the current row is scattered, into registers: with one stage and two barriers per
-//    row the loads used to start only after the scatter had drained, and the bytes in flight per CU (two blocks x 32 KB, half of
-//    the time) covered about half of what the memory latency needs at full rate;
+// Round 4 (the form of round 3 moved 4.14 GB in 1.355 ms = 0.38 of the HBM peak, profiles/r03h_*; with the loads alone or the
+// stores alone the first form of this round took 0.73 and 0.71 ms, profiles/notes_r04_bin_move.md):
+//  * the waves of a block are SPECIALISED: the producer waves only load (16-byte loads, two rows in flight in registers, written
+//    to one of two LDS stages), the consumer waves only read the stage and store — fire and forget, they never wait for memory
+//    (a wave with loads AND stores in flight can only wait for "everything": one counter counts both); one barrier per row
+//    hands a stage over;
+//  * a consumer keeps everything about its destination positions in REGISTERS (source index in the tile, class, row counts packed
+//    in one word; stride; the running plane offsets of the polygon in hand): a row costs it one 8-byte LDS read and two stores
+//    per position instead of nine LDS look-ups;
+//  * the stage holds (x, y) side by side, so that the random-bank read of a position is ONE ds_read_b64;
+//  * the slots come from an eight-ballot class match (wave_match_class) and one prefix pass over the waves per class, two
+//    barriers per 1024 pairs, where round 3 looped over the distinct classes of a wave and summed the earlier waves per lane;
 //  * consecutive tiles go to the SAME XCD (block b of a launch runs on XCD b % 8): the run a tile contributes to a bin's row is
-//    about 21 floats and ends inside a cache line that the NEXT tile continues — written from the same L2 the two partial lines
-//    can merge before they leave for HBM.
+//    about 42 floats and ends inside a cache line that the NEXT tile continues — written from the same L2 the two partial lines
+//    merge before they leave for HBM (WRITE_SIZE 2.07 -> 1.69 GB for 1.55 GB of vertices);
 //  * plane positions are element offsets from the bins' block in 32 bits (Off = uint32_t; a block of 16 GiB or more takes the
-//    64-bit instance): at 16 waves per block the kernel must stay within 64 registers for two blocks to share a CU.
-template <typename Off>
-__global__ __launch_bounds__(kBinBlock, 2 * kBinWaves / 4) void poly_bin_move_kernel(BinMoveArgs A)
+//    64-bit instance);
+//  * the tile is 8192 pairs, one block per CU (134 KB of LDS): what limits the pass now is how well DRAM takes the WRITES —
+//    with the loads switched off the stores alone take 0.70 ms for 1.6 GB (2.3 TB/s), folded into a 32 MB window that L2 absorbs
+//    0.35 ms, and 16 bins (runs of 1 KB instead of 84 B) 0.40 ms — so the longer run per (tile, bin, row) is worth more than
+//    the second block per CU that a 4096-pair tile allows (same box: 1.27 -> 1.15 ms; whole call 1.70 -> 1.38 ms).
+typedef float v4f_u __attribute__((ext_vector_type(4), aligned(4)));  // four floats at any 4-byte boundary (a row of the padded batch starts anywhere)
+#ifndef C2D_MOVE_PRODUCER_WAVES
+#define C2D_MOVE_PRODUCER_WAVES 8
+#endif
+constexpr int kProducerWaves = C2D_MOVE_PRODUCER_WAVES, kConsumerThreads = kBinBlock - 64 * kProducerWaves;
+constexpr int kMovePos = (kMoveTile + kConsumerThreads - 1) / kConsumerThreads;  // destination positions per consumer thread
+constexpr int kMoveVec = kMoveTile / 4 / (64 * kProducerWaves);                  // 16-byte loads per producer thread, row and plane
+static_assert(kMoveVec * 4 * 64 * kProducerWaves == kMoveTile, "the producers' loads tile the row");
+
+// the lanes of the wave (with ok) that hold the same 8-bit class as this lane: eight ballots, no loop over classes
+C2D_DEV unsigned long long wave_match_class(uint32_t c, bool ok)
 {
-    __shared__ float s_stage[2][kMoveTile];       // one vertex row of the tile, x and y
-    // per-wave class counts of the 1024 pairs in hand: only needed while the slots are computed, so they live in the stage
-    uint16_t (*s_wc)[256] = reinterpret_cast<uint16_t (*)[256]>(&s_stage[0][0]);
-    static_assert(sizeof(uint16_t) * kBinWaves * 256 <= sizeof(float) * kMoveTile, "s_wc fits the stage");
-    __shared__ uint32_t s_slot[kMoveTile];        // slot of local pair li within its bin
-    __shared__ uint16_t s_cls[kMoveTile];         // its class, 0xffff = bad counts
-    __shared__ uint16_t s_sorted[kMoveTile];      // local pair at position sp of the tile's (class, slot) order
+    unsigned long long peers = __ballot(ok);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const bool bit = ((c >> b) & 1u) != 0;
+        const unsigned long long m = __ballot(bit);
+        peers &= bit ? m : ~m;
+    }
+    return peers;
+}
+
+template <typename Off>
+__global__ __launch_bounds__(kBinBlock, (kMoveTile <= 4096 ? 2 : 1) * kBinWaves / 4) void poly_bin_move_kernel(BinMoveArgs A)
+{
+    // two stages, each one vertex row of the tile as (x, y) pairs.  Until the rows start they hold the tables of the slot
+    // computation: per-wave class counts and prefixes in stage 0, s_slot / s_cls / s_sorted (32 KB) in stage 1
+    __shared__ __attribute__((aligned(16))) float2 s_stage[2][kMoveTile];
+    uint16_t (*s_wcnt)[256] = reinterpret_cast<uint16_t (*)[256]>(&s_stage[0][0]);               // [wave][class] pairs of the class in the wave
+    uint16_t (*s_wpre)[256] = reinterpret_cast<uint16_t (*)[256]>(&s_stage[0][0]) + kBinWaves;   // [wave][class] ... in the tile before the wave
+    static_assert(2 * sizeof(uint16_t) * kBinWaves * 256 <= sizeof(float2) * kMoveTile, "the wave tables fit stage 0");
+    uint32_t* s_slot = reinterpret_cast<uint32_t*>(&s_stage[1][0]);                       // slot of local pair li within its bin
+    uint16_t* s_cls = reinterpret_cast<uint16_t*>(&s_stage[1][kMoveTile / 2]);            // its class, 0xffff = bad counts
+    uint16_t* s_sorted = reinterpret_cast<uint16_t*>(&s_stage[1][kMoveTile / 2]) + kMoveTile;  // local pair at position sp of the tile's (class, slot) order
     __shared__ uint32_t s_cbase[257];             // first position of class c in that order; [256] = valid pairs of the tile
     __shared__ uint32_t s_first[256];             // slot of the tile's first pair of class c
     __shared__ uint32_t s_run[256];               // pairs of class c in the tile's earlier sub-blocks
     __shared__ Off s_plane[4][256];               // ax, ay, bx, by of the class's bin, as element offsets from A.base
     __shared__ uint32_t s_stride[256];
     __shared__ uint8_t s_rows[2][256];
-    const uint32_t t = threadIdx.x, wave = t >> 6;
+    const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const uint32_t tile = (blockIdx.x & 7u) * A.tiles_per_xcd + (blockIdx.x >> 3);
     if (tile >= A.n_tiles) return;  // (block-uniform)
     const size_t tile0 = (size_t)tile * kMoveTile;
@@ -534,14 +572,24 @@ __global__ __launch_bounds__(kBinBlock, 2 * kBinWaves / 4) void poly_bin_move_ke
         s_run[c] = 0;
         s_cbase[c + 1] = cnt;  // counts for now
     }
-    for (int i = t; i < kBinWaves * 256; i += kBinBlock) (&s_wc[0][0])[i] = 0;
+    for (int i = t; i < kBinWaves * 256; i += kBinBlock) (&s_wcnt[0][0])[i] = 0;
     __syncthreads();
-    if (t == 0) {  // counts -> first positions: s_cbase[c + 1] holds the count of class c, s_cbase[0] = 0 (256 serial adds)
-        s_cbase[0] = 0;
-        for (int c = 0; c < 256; c++) s_cbase[c + 1] += s_cbase[c];
+    if (t < 64) {  // counts -> first positions (s_cbase[c + 1] holds the count of class c): one wave, four classes per lane
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { v[q] = s_cbase[4 * t + q + 1]; sum += v[q]; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
+            if (t >= (uint32_t)off) incl += o;
+        }
+        uint32_t run = incl - sum;  // classes before this lane's four
+        if (t == 0) s_cbase[0] = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { run += v[q]; s_cbase[4 * t + q + 1] = run; }
     }
-    __syncthreads();
-    // ---- slots, index, and the tile's (class, slot) order
+    // ---- slots, index, and the tile's (class, slot) order: 1024 pairs at a time
     for (int sub = 0; sub < kMoveSub; sub++) {
         const uint32_t li = sub * kBinBlock + t;
         const size_t i = tile0 + li;
@@ -554,17 +602,30 @@ __global__ __launch_bounds__(kBinBlock, 2 * kBinWaves / 4) void poly_bin_move_ke
             c = bin_class(ka, kb, A.rows, A.g);
         }
         const bool ok = c != 0xffffffffu;
-        const uint32_t rank = wave_class_rank(c, ok, s_wc[wave]);
+        const unsigned long long peers = wave_match_class(c, ok);
+        const uint32_t rank = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+        if (ok && rank == 0) s_wcnt[wave][c] = (uint16_t)__popcll(peers);  // the class's first lane in the wave
+        __syncthreads();  // (also orders the s_cbase scan above before its first use)
+        if (t < 256) {  // per class: counts of the waves -> pairs of the class in the tile before each wave; the counts are cleared for the next round
+            uint32_t run = s_run[t];
+#pragma unroll
+            for (int w = 0; w < kBinWaves; w++) {
+                const uint32_t v = s_wcnt[w][t];
+                s_wcnt[w][t] = 0;
+                s_wpre[w][t] = (uint16_t)run;
+                run += v;
+            }
+            s_run[t] = run;
+        }
         __syncthreads();
         s_cls[li] = ok ? (uint16_t)c : (uint16_t)0xffff;
         if (in) {
             uint32_t pos = 0xffffffffu;
             if (ok) {
-                uint32_t before = s_run[c];  // pairs of the class in earlier sub-blocks, then in earlier waves of this one
-                for (uint32_t w = 0; w < wave; w++) before += s_wc[w][c];
-                const uint32_t slot = s_first[c] + before + rank;
+                const uint32_t in_tile = (uint32_t)s_wpre[wave][c] + rank;  // pairs of the class earlier in the tile
+                const uint32_t slot = s_first[c] + in_tile;
                 s_slot[li] = slot;
-                s_sorted[s_cbase[c] + (slot - s_first[c])] = (uint16_t)li;
+                s_sorted[s_cbase[c] + in_tile] = (uint16_t)li;
                 const uint32_t bin = A.class_to_bin[c];
                 pos = A.pair_base[bin] + slot;
                 const BinDesc D = A.table[bin];
@@ -575,75 +636,134 @@ __global__ __launch_bounds__(kBinBlock, 2 * kBinWaves / 4) void poly_bin_move_ke
             }
             A.index[i] = pos;
         }
-        __syncthreads();
-        if (t < 256) {
-            uint32_t add = 0;
-#pragma unroll
-            for (int w = 0; w < kBinWaves; w++) add += s_wc[w][t];
-            s_run[t] += add;
-        }
-        __syncthreads();
-        for (int i2 = t; i2 < kBinWaves * 256; i2 += kBinBlock) (&s_wc[0][0])[i2] = 0;
-        __syncthreads();
     }
+    __syncthreads();
     const uint32_t n_valid = s_cbase[256];
     const uint32_t here = (uint32_t)((A.n - tile0) < (size_t)kMoveTile ? (A.n - tile0) : (size_t)kMoveTile);
-    // ---- this thread's four destination positions, in registers
-    uint32_t d_li[kMoveSub], d_stride[kMoveSub], d_rows[kMoveSub];
-    Off d_x[2][kMoveSub], d_y[2][kMoveSub];
+    const int n_rows = 2 * A.rows;  // rows of polygon A, then of polygon B
+    if (wave >= (uint32_t)kProducerWaves) {
+        // ---- consumer: this thread's destination positions, in registers.  meta = li | class << 16 | rows_a << 24 | rows_b << 28
+        // (row counts 1..16 stored as 0..15; a position without a pair has stride 0 and never stores: see `live`)
+        const uint32_t tc = t - 64 * kProducerWaves;
+        uint32_t d_meta[kMovePos], d_stride[kMovePos], d_slot[kMovePos];
+        unsigned live = 0;  // bit j: position j holds a pair
 #pragma unroll
-    for (int j = 0; j < kMoveSub; j++) {
-        const uint32_t sp = (uint32_t)j * kBinBlock + t;
-        d_li[j] = 0; d_stride[j] = 0; d_rows[j] = 0;  // rows 0 / 0: nothing to store
-        d_x[0][j] = d_y[0][j] = d_x[1][j] = d_y[1][j] = 0;
-        if (sp < n_valid) {
-            const uint32_t li = s_sorted[sp];
-            const uint32_t c = s_cls[li];
-            const uint32_t slot = s_slot[li];
-            d_li[j] = li;
-            d_stride[j] = s_stride[c];
-            d_rows[j] = (uint32_t)s_rows[0][c] | ((uint32_t)s_rows[1][c] << 8);
-            d_x[0][j] = s_plane[0][c] + slot; d_y[0][j] = s_plane[1][c] + slot;
-            d_x[1][j] = s_plane[2][c] + slot; d_y[1][j] = s_plane[3][c] + slot;
+        for (int j = 0; j < kMovePos; j++) {
+            const uint32_t sp = (uint32_t)j * kConsumerThreads + tc;
+            d_meta[j] = 0; d_stride[j] = 0; d_slot[j] = 0;
+            if (sp < n_valid) {
+                const uint32_t li = s_sorted[sp];
+                const uint32_t c = s_cls[li];
+                d_slot[j] = s_slot[li];
+                d_stride[j] = s_stride[c];
+                d_meta[j] = li | (c << 16) | ((uint32_t)(s_rows[0][c] - 1) << 24) | ((uint32_t)(s_rows[1][c] - 1) << 28);
+                live |= 1u << j;
+            }
         }
-    }
-    // ---- every vertex row of every plane through the stage; the next row is on its way while this one is scattered
-    float nx_[kMoveSub], ny_[kMoveSub];
-    auto fetch = [&](int poly, int r) {
-        const size_t row = ((size_t)poly * A.rows + r) * A.n + tile0;
+        __syncthreads();  // (0) the tables in the stages have been read: the producers may fill them
 #pragma unroll
-        for (int e = 0; e < kMoveSub; e++) {
-            const uint32_t li = (uint32_t)e * kBinBlock + t;
-            nx_[e] = li < here ? __builtin_nontemporal_load(A.vx + row + li) : 0.0f;
-            ny_[e] = li < here ? __builtin_nontemporal_load(A.vy + row + li) : 0.0f;
+        for (int poly = 0; poly < 2; poly++) {
+            Off d_x[kMovePos], d_y[kMovePos];
+#pragma unroll
+            for (int j = 0; j < kMovePos; j++) {
+                const uint32_t c = (d_meta[j] >> 16) & 0xffu;
+                d_x[j] = s_plane[2 * poly][c] + d_slot[j];
+                d_y[j] = s_plane[2 * poly + 1][c] + d_slot[j];
+            }
+#pragma nounroll
+            for (int r = 0; r < A.rows; r++) {
+                const int it = poly * A.rows + r;
+                __syncthreads();  // (it + 1) stage it & 1 holds row it
+                const float2* sv = &s_stage[it & 1][0];
+#pragma unroll
+                for (int j = 0; j < kMovePos; j++) {
+                    const uint32_t rows_here = ((d_meta[j] >> (24 + 4 * poly)) & 0xfu) + 1u;
+#ifdef C2D_MOVE_NO_STORE  // (experiment: how long do the loads alone take)
+                    const float2 v = sv[d_meta[j] & 0xffffu];
+                    if (((live >> j) & 1u) && (uint32_t)r < rows_here && v.x == 1.2345e-30f && v.y == 5.4321e-30f) A.base[d_x[j]] = 0.0f;
+#else
+                    if (((live >> j) & 1u) && (uint32_t)r < rows_here) {
+                        const float2 v = sv[d_meta[j] & 0xffffu];
+#if defined(C2D_MOVE_STORE_WINDOW)      // (experiment: the same stores folded into a 32 MB window: is it DRAM or the way there?)
+                        A.base[d_x[j] & 0x7fffffu] = v.x;
+                        A.base[d_y[j] & 0x7fffffu] = v.y;
+#elif defined(C2D_MOVE_NT_STORE)
+                        __builtin_nontemporal_store(v.x, A.base + d_x[j]);
+                        __builtin_nontemporal_store(v.y, A.base + d_y[j]);
+#else
+                        A.base[d_x[j]] = v.x;
+                        A.base[d_y[j]] = v.y;
+#endif
+                    }
+#endif
+                    d_x[j] += d_stride[j];
+                    d_y[j] += d_stride[j];
+                }
+            }
+        }
+        return;
+    }
+    // ---- producer: rows it, it + 1 in flight in registers; row it goes to stage it & 1 once it has arrived.  The loop exists
+    // twice: for a whole tile (plain 16-byte loads, nothing to decide per lane) and for the batch's last, partial tile
+    auto produce = [&](auto full_const) {
+        constexpr bool FULL = decltype(full_const)::value;
+        float4 bx_[2][kMoveVec], by_[2][kMoveVec];
+        auto fetch = [&](int it, float4 (&fx)[kMoveVec], float4 (&fy)[kMoveVec]) {
+            const size_t row = (size_t)it * A.n + tile0;   // (it = poly * rows + r: the planes are [2][rows][n])
+#pragma unroll
+            for (int e = 0; e < kMoveVec; e++) {
+                const uint32_t li = 4u * ((uint32_t)e * 64 * kProducerWaves + t);
+#ifdef C2D_MOVE_NO_LOAD  // (experiment: how long do the stores alone take)
+                if (true) {
+                    fx[e] = make_float4((float)li, 1.0f, 2.0f, (float)it);
+                    fy[e] = make_float4((float)li, 3.0f, 4.0f, (float)it);
+                } else
+#endif
+                if constexpr (FULL) {
+                    const v4f_u lx = __builtin_nontemporal_load(reinterpret_cast<const v4f_u*>(A.vx + row + li));
+                    const v4f_u ly = __builtin_nontemporal_load(reinterpret_cast<const v4f_u*>(A.vy + row + li));
+                    fx[e] = make_float4(lx.x, lx.y, lx.z, lx.w);
+                    fy[e] = make_float4(ly.x, ly.y, ly.z, ly.w);
+                } else {
+                    float ax[4], ay[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        ax[q] = li + q < here ? A.vx[row + li + q] : 0.0f;
+                        ay[q] = li + q < here ? A.vy[row + li + q] : 0.0f;
+                    }
+                    fx[e] = make_float4(ax[0], ax[1], ax[2], ax[3]);
+                    fy[e] = make_float4(ay[0], ay[1], ay[2], ay[3]);
+                }
+            }
+        };
+        auto put = [&](int it, const float4 (&fx)[kMoveVec], const float4 (&fy)[kMoveVec]) {
+            float4* sv = reinterpret_cast<float4*>(&s_stage[it & 1][0]);  // two (x, y) pairs per float4
+#pragma unroll
+            for (int e = 0; e < kMoveVec; e++) {
+                const uint32_t li = 4u * ((uint32_t)e * 64 * kProducerWaves + t);
+                sv[li / 2] = make_float4(fx[e].x, fy[e].x, fx[e].y, fy[e].y);
+                sv[li / 2 + 1] = make_float4(fx[e].z, fy[e].z, fx[e].w, fy[e].w);
+            }
+        };
+        // n_rows is even (two polygons).  Every step issues its fetch — past the end it re-reads the last row into registers nobody
+        // reads — so that the number of loads in flight at each wait is the same on every path and the wait for row `it` can
+        // leave row it + 1's loads outstanding (a conditional fetch makes the compiler wait for everything)
+        const int last = n_rows - 1;
+        fetch(0, bx_[0], by_[0]);
+        fetch(1, bx_[1], by_[1]);
+        __syncthreads();  // (0)
+#pragma nounroll
+        for (int it = 0; it < n_rows; it += 2) {
+            put(it, bx_[0], by_[0]);
+            fetch(it + 2 < last ? it + 2 : last, bx_[0], by_[0]);
+            __syncthreads();  // (it + 1)
+            put(it + 1, bx_[1], by_[1]);
+            fetch(it + 3 < last ? it + 3 : last, bx_[1], by_[1]);
+            __syncthreads();  // (it + 2)
         }
     };
-    fetch(0, 0);
-#pragma unroll
-    for (int poly = 0; poly < 2; poly++) {
-#pragma nounroll
-        for (int r = 0; r < A.rows; r++) {
-#pragma unroll
-            for (int e = 0; e < kMoveSub; e++) {
-                s_stage[0][e * kBinBlock + t] = nx_[e];
-                s_stage[1][e * kBinBlock + t] = ny_[e];
-            }
-            __syncthreads();
-            if (r + 1 < A.rows) fetch(poly, r + 1);
-            else if (poly == 0) fetch(1, 0);
-#pragma unroll
-            for (int j = 0; j < kMoveSub; j++) {
-                const uint32_t rows_here = (d_rows[j] >> (8 * poly)) & 0xffu;
-                if ((uint32_t)r < rows_here) {
-                    A.base[d_x[poly][j]] = s_stage[0][d_li[j]];
-                    A.base[d_y[poly][j]] = s_stage[1][d_li[j]];
-                }
-                d_x[poly][j] += d_stride[j];
-                d_y[poly][j] += d_stride[j];
-            }
-            __syncthreads();
-        }
-    }
+    if (here == (uint32_t)kMoveTile) produce(std::true_type{});
+    else produce(std::false_type{});
 }
 
 __global__ __launch_bounds__(256) void poly_bins_results_kernel(const uint8_t* __restrict__ out_all, const uint32_t* __restrict__ index, size_t n,
@@ -667,6 +787,7 @@ struct c2d_poly_bins {
     BinDesc* d_table = nullptr;
     uint32_t* d_tile_bin = nullptr;
     size_t n_tiles = 0, pairs = 0, bytes = 0;
+    bool table_in_block = false;      // d_table / d_tile_bin live inside d_block (c2d_poly_bins_from_padded): nothing to free
     // handles made by c2d_poly_bins_from_padded own their data
     void* d_block = nullptr;
     uint8_t* d_out_all = nullptr;     // inside d_block: every bin's results, in bin order
@@ -678,7 +799,12 @@ struct c2d_poly_bins {
 namespace {
 
 // the launch table as the test kernel wants it: polygon A of an entry is the one with more rows
-int upload_table(c2d_ctx* ctx, c2d_poly_bins* B)
+// in_block: where the table and the tile list go (device memory inside the handle's own block, table first, tile list at
+// in_block + tile_list_offset; see table_bytes below), or nullptr = two allocations of their own (c2d_poly_bins_create);
+// s: the stream of the uploads (synchronised before this returns: the host vectors are locals)
+size_t table_bytes(size_t n_bins) { return (n_bins * sizeof(BinDesc) + 255) / 256 * 256; }
+
+int upload_table(c2d_ctx* ctx, c2d_poly_bins* B, char* in_block = nullptr, hipStream_t s = nullptr)
 {
     std::vector<BinDesc> table(B->bins.size());
     std::vector<uint32_t> tile_bin;
@@ -709,6 +835,15 @@ int upload_table(c2d_ctx* ctx, c2d_poly_bins* B)
         B->bytes += s.n * ((size_t)(s.rows_a + s.rows_b) * 8 + (s.d_ka ? 2 : 0) + 1);
     }
     B->n_tiles = tiles;
+    if (in_block) {
+        B->table_in_block = true;
+        B->d_table = reinterpret_cast<BinDesc*>(in_block);
+        B->d_tile_bin = reinterpret_cast<uint32_t*>(in_block + table_bytes(table.size()));
+        if (!table.empty()) C2D_HIP(ctx, hipMemcpyAsync(B->d_table, table.data(), table.size() * sizeof(BinDesc), hipMemcpyHostToDevice, s));
+        if (tiles) C2D_HIP(ctx, hipMemcpyAsync(B->d_tile_bin, tile_bin.data(), tiles * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        C2D_HIP(ctx, hipStreamSynchronize(s));
+        return C2D_OK;
+    }
     if (!table.empty()) {
         C2D_HIP(ctx, hipMalloc(&B->d_table, table.size() * sizeof(BinDesc)));
         C2D_HIP(ctx, hipMemcpy(B->d_table, table.data(), table.size() * sizeof(BinDesc), hipMemcpyHostToDevice));
@@ -723,8 +858,8 @@ int upload_table(c2d_ctx* ctx, c2d_poly_bins* B)
 void release(c2d_poly_bins* B)
 {
     if (!B) return;
-    if (B->d_table) (void)hipFree(B->d_table);
-    if (B->d_tile_bin) (void)hipFree(B->d_tile_bin);
+    if (B->d_table && !B->table_in_block) (void)hipFree(B->d_table);
+    if (B->d_tile_bin && !B->table_in_block) (void)hipFree(B->d_tile_bin);
     if (B->d_block) (void)hipFree(B->d_block);
     delete B;
 }
@@ -836,23 +971,31 @@ int c2d_poly_bins_from_padded(c2d_ctx* ctx, const float* d_vx, const float* d_vy
         hipError_t e__ = (call);                                                                 \
         if (e__ != hipSuccess) return fail(c2d::fail_hip(ctx, e__, #call, __FILE__, __LINE__));  \
     } while (0)
-    // ---- 1. pairs per (tile of 4096, class), prefixes over the tiles, class totals
+    // ---- 1. pairs per (tile, class), prefixes over the tiles, class totals
     const size_t n_tiles = (n + kMoveTile - 1) / kMoveTile;
     const size_t n_chunks = (n_tiles + kScanChunk - 1) / kScanChunk;
-    uint32_t* d_hist = nullptr;   // [n_tiles][256] counts -> prefixes | [256] totals + 1 word of bad-count waves | [n_chunks][256] chunk sums
-    C2D_BIN_HIP(hipMalloc(&d_hist, (n_tiles * 256 + 257 + n_chunks * 256) * sizeof(uint32_t)));
+    // scratch of the pass, from the ctx (grown on demand, kept between calls; this call is ordered on `s` and ends synchronised):
+    // [n_tiles][256] counts -> prefixes | [256] totals + 1 word of bad-count waves | [n_chunks][256] chunk sums | the move kernel's table
+    const size_t hist_words = n_tiles * 256 + 257 + n_chunks * 256;
+    const size_t off_plain = (hist_words * sizeof(uint32_t) + 255) / 256 * 256;
+    const size_t scratch_need = off_plain + 256 * sizeof(BinDesc);
+    if (int rc = workspace_acquire(ctx, s, true)) return fail(rc);
+    if (ctx->scratch_bytes < scratch_need) {
+        if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+        ctx->d_scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        C2D_BIN_HIP(hipMalloc(&ctx->d_scratch, scratch_need));
+        ctx->scratch_bytes = scratch_need;
+    }
+    uint32_t* d_hist = static_cast<uint32_t*>(ctx->d_scratch);
     uint32_t* d_totals = d_hist + n_tiles * 256;
     uint32_t* d_chunk_sums = d_totals + 257;
     uint32_t hist[257];
-    hipError_t e = hipMemsetAsync(d_totals, 0, (257 + n_chunks * 256) * sizeof(uint32_t), s);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(poly_bin_count_kernel, dim3((unsigned)n_tiles), dim3(kBinBlock), 0, s, d_k, n, rows, granularity, d_hist, d_chunk_sums, d_totals + 256);
-        hipLaunchKernelGGL(poly_bin_scan_kernel, dim3((unsigned)n_chunks), dim3(256), 0, s, d_hist, (uint32_t)n_tiles, d_chunk_sums, d_totals);
-        e = hipMemcpyAsync(hist, d_totals, sizeof hist, hipMemcpyDeviceToHost, s);
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) { (void)hipFree(d_hist); return fail(c2d::fail_hip(ctx, e, "class count", __FILE__, __LINE__)); }
-    struct HistGuard { uint32_t* p; ~HistGuard() { (void)hipFree(p); } } hist_guard{d_hist};
+    C2D_BIN_HIP(hipMemsetAsync(d_totals, 0, (257 + n_chunks * 256) * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(poly_bin_count_kernel, dim3((unsigned)n_tiles), dim3(kBinBlock), 0, s, d_k, n, rows, granularity, d_hist, d_chunk_sums, d_totals + 256);
+    hipLaunchKernelGGL(poly_bin_scan_kernel, dim3((unsigned)n_chunks), dim3(256), 0, s, d_hist, (uint32_t)n_tiles, d_chunk_sums, d_totals);
+    C2D_BIN_HIP(hipMemcpyAsync(hist, d_totals, sizeof hist, hipMemcpyDeviceToHost, s));
+    C2D_BIN_HIP(hipStreamSynchronize(s));
     lap("count + scan + read-back");
     B->had_bad_counts = hist[256] != 0;
     // ---- 2. layout of the block: per bin ax, ay, bx, by (stride = n rounded up to 64 elements, every plane 256-byte
@@ -899,6 +1042,11 @@ int c2d_poly_bins_from_padded(c2d_ctx* ctx, const float* d_vx, const float* d_vy
     bytes = off_base + (n_bins + 1) * sizeof(uint32_t);
     const size_t off_c2b = align_up(bytes, 256);
     bytes = off_c2b + 256 * sizeof(uint16_t);
+    // the test kernel's launch table and tile list (upload_table) live in the block too: one allocation per handle
+    size_t test_tiles = 0;
+    for (const c2d_poly_bin& b : B->bins) test_tiles += (b.n + 63) / 64;
+    const size_t off_table = align_up(bytes, 256);
+    bytes = off_table + table_bytes(n_bins) + test_tiles * sizeof(uint32_t);
     lap("host layout");
     hipError_t me = hipMalloc(&B->d_block, bytes);
     lap("hipMalloc of the block");
@@ -919,7 +1067,7 @@ int c2d_poly_bins_from_padded(c2d_ctx* ctx, const float* d_vx, const float* d_vy
         d.d_out = B->d_out_all + pair_base[b];
         d.stride = p.stride;
     }
-    int st = upload_table(ctx, B);
+    int st = upload_table(ctx, B, base + off_table, s);
     if (st != C2D_OK) return fail(st);
     lap("launch table upload");
     // the move kernel's view of the bins: polygon A = the input's polygon A
@@ -930,9 +1078,7 @@ int c2d_poly_bins_from_padded(c2d_ctx* ctx, const float* d_vx, const float* d_vy
         t.ax = d.d_ax; t.ay = d.d_ay; t.bx = d.d_bx; t.by = d.d_by; t.ka = d.d_ka; t.kb = d.d_kb; t.out = d.d_out;
         t.n = (uint32_t)d.n; t.stride = (uint32_t)d.stride; t.tile0 = 0; t.rows_a = (uint16_t)d.rows_a; t.rows_b = (uint16_t)d.rows_b;
     }
-    BinDesc* d_plain = nullptr;
-    C2D_BIN_HIP(hipMalloc(&d_plain, std::max<size_t>(n_bins, 1) * sizeof(BinDesc)));
-    struct PlainGuard { BinDesc* p; ~PlainGuard() { (void)hipFree(p); } } plain_guard{d_plain};
+    BinDesc* d_plain = reinterpret_cast<BinDesc*>(static_cast<char*>(ctx->d_scratch) + off_plain);  // (at most 256 bins: one per class)
     if (n_bins) C2D_BIN_HIP(hipMemcpyAsync(d_plain, plain.data(), n_bins * sizeof(BinDesc), hipMemcpyHostToDevice, s));
     // ---- 3. move the vertices
     C2D_BIN_HIP(hipMemsetAsync(B->d_out_all, 0, pairs, s));
@@ -953,6 +1099,7 @@ int c2d_poly_bins_from_padded(c2d_ctx* ctx, const float* d_vx, const float* d_vy
     if (bytes < (16ull << 30)) hipLaunchKernelGGL(poly_bin_move_kernel<uint32_t>, dim3(A.tiles_per_xcd * 8u), dim3(kBinBlock), 0, s, A);  // (n < 2^32)
     else hipLaunchKernelGGL(poly_bin_move_kernel<uint64_t>, dim3(A.tiles_per_xcd * 8u), dim3(kBinBlock), 0, s, A);
     C2D_BIN_HIP(hipStreamSynchronize(s));  // (the host vectors above must outlive their copies)
+    workspace_release(ctx, s, true);
     lap("move kernel");
 #undef C2D_BIN_HIP
     if (B->had_bad_counts) {

@@ -234,7 +234,8 @@ int c2d_sat_poly_pairs_rows(c2d_ctx* ctx, const float* d_vx, const float* d_vy, 
  *                          device: polygon sizes are rounded up to a multiple of `granularity`
  *                          rows (1 = one bin per (ka, kb), no padding at all; 4 = at most 16 bins),
  *                          the bins live in ONE device block owned by the handle.  This moves
- *                          every vertex once (about 2 ms per 1e7 pairs, six to eight tests' worth): it pays when the
+ *                          every vertex once (about 1.3 ms per 1e7 pairs, what eight tests save against the padded layout;
+ *                          profiles/notes_r04_bin_move.md): it pays when the
  *                          batch is tested more than once or as a converter for stored datasets;
  *                          a producer that can write bins directly should.  Synchronous; a vertex
  *                          count outside 1..rows is refused (C2D_ERR_INVALID_ARG, no handle).
