@@ -154,6 +154,8 @@ _SIGNATURES = {
     "c2d_mc_poly_scenes": (C.c_int, [C.c_void_p, C.POINTER(_McPolyScenesArgs), C.c_void_p]),
     "c2d_sample_scenes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_float,
                                     C.c_uint64, C.c_uint64, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "c2d_uniform_table_minstd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint64, C.c_void_p]),
+    "c2d_sqrt_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "c2d_dist_unique_id": (C.c_int, [C.c_void_p]),
     "c2d_dist_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "c2d_dist_init_file": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_double, C.POINTER(C.c_void_p)]),
@@ -163,6 +165,8 @@ _SIGNATURES = {
     "c2d_dist_all_reduce_sum_u64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "c2d_dist_broadcast_u64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "c2d_dist_barrier": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "c2d_dist_stream_synchronize": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "c2d_dist_timed_out": (C.c_int, [C.c_void_p]),
     "c2d_dist_destroy": (C.c_int, [C.c_void_p]),
     "c2d_calc_slack": (C.c_float, [C.c_uint32, C.c_uint32]),
     "c2d_get_bin": (C.c_int, [C.c_float, C.POINTER(C.c_float), C.c_uint32]),
@@ -247,6 +251,14 @@ class Dist:
 
     def barrier(self, stream: int = 0):
         self.eng._check(self.eng.lib.c2d_dist_barrier(self.h, C.c_void_p(stream)), "c2d_dist_barrier")
+
+    def synchronize(self, stream: int = 0):
+        """wait for the collectives queued on `stream` under the watchdog (c2d_dist_stream_synchronize)"""
+        self.eng._check(self.eng.lib.c2d_dist_stream_synchronize(self.h, C.c_void_p(stream)), "c2d_dist_stream_synchronize")
+
+    @property
+    def timed_out(self) -> bool:
+        return bool(self.eng.lib.c2d_dist_timed_out(self.h))
 
     def close(self):
         if self.h:
@@ -548,6 +560,14 @@ class Engine:
         self._check(self.lib.c2d_sample_scenes(self.h, _ptr_of(poses), num_poses, _ptr_of(std_devs), num_std_devs, robot_w,
                                                robot_h, spread, seed, scene_id_base, n_scenes, _ptr_of(scenes),
                                                C.c_void_p(stream)), "c2d_sample_scenes")
+
+    def uniform_table_minstd(self, out, rows: int, dims: int, lo, hi, first_draw: int = 0, stream: int = 0):
+        lo_, hi_ = np.ascontiguousarray(lo, dtype=np.float32), np.ascontiguousarray(hi, dtype=np.float32)
+        self._check(self.lib.c2d_uniform_table_minstd(self.h, _ptr_of(out), rows, dims, lo_.ctypes.data_as(C.POINTER(C.c_float)),
+                                                      hi_.ctypes.data_as(C.POINTER(C.c_float)), first_draw, C.c_void_p(stream)), "c2d_uniform_table_minstd")
+
+    def sqrt_f32(self, src, dst, n: int, stream: int = 0):
+        self._check(self.lib.c2d_sqrt_f32(self.h, _ptr_of(src), _ptr_of(dst), n, C.c_void_p(stream)), "c2d_sqrt_f32")
 
     def calc_slack(self, n: int, k: int) -> float:
         return float(self.lib.c2d_calc_slack(n, k))

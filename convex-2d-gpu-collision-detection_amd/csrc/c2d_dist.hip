@@ -21,7 +21,8 @@
 // Watchdog: ncclCommInitRank and the first collective block until every rank has arrived.  Both run on a helper thread
 // here and the caller waits with a deadline (timeout_s of c2d_dist_init_file, $C2D_DIST_TIMEOUT_S or 300 s for
 // c2d_dist_init): a rank whose peers never show up gets C2D_ERR_DIST instead of hanging forever.  The helper thread is
-// left behind inside RCCL in that case — the process is expected to report the error and end (the drivers do).
+// left behind inside RCCL in that case — the process is expected to report the error and end WITHOUT running exit handlers
+// (the drivers _exit: the HIP / ROCr teardown of a normal exit would race the abandoned thread).
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <rccl/rccl.h>
@@ -161,7 +162,9 @@ struct c2d_dist {
     int rank = 0, world = 1;
     ncclComm_t comm = nullptr;
     double timeout_s = 300.0;
-    std::string error;     // set by the helper thread of the watchdog
+    std::string error;     // set by the helper thread of the watchdog (ncclCommInitRank only)
+    bool timed_out = false; // a watched call ran out of time: a helper thread is still inside RCCL / HIP with this communicator,
+                            // which must neither be used nor destroyed any more
 #ifdef C2D_DIST_REHEARSAL
     std::string base;      // file transport: path prefix of the exchange files
     uint64_t seq = 0;      // file transport: collective sequence number
@@ -293,7 +296,7 @@ int c2d_dist_init_file(c2d_ctx* ctx, int rank, int world_size, const char* path,
     // every rank has read the id once the first collective completes: rank 0 then removes the file
     st = c2d_dist_barrier(*out, nullptr);
     if (st != C2D_OK) {
-        if (st != C2D_ERR_DIST) c2d_dist_destroy(*out);  // (after a watchdog timeout the communicator is left to its thread)
+        if (!(*out)->timed_out) c2d_dist_destroy(*out);  // (after a watchdog time-out the communicator is left to its thread; any other failure frees it)
         *out = nullptr;
         return st;
     }
@@ -362,26 +365,42 @@ int c2d_dist_broadcast_u64(c2d_dist* d, unsigned long long* d_buf, size_t count,
 }
 
 // One-word all-reduce + stream synchronise, under the watchdog: a collective that a peer never joins would otherwise
-// hold hipStreamSynchronize for ever.  The word and the status live in a block the helper thread co-owns.
+// hold hipStreamSynchronize for ever.  The helper thread touches nothing of the ctx: its status and error text live in a
+// block it co-owns, and the caller copies them into the ctx only when the helper finished in time (after a time-out the
+// helper may still be running while the caller reports, or after the caller has destroyed the ctx).
 int c2d_dist_barrier(c2d_dist* d, c2d_stream stream)
 {
     if (!d) return C2D_ERR_INVALID_ARG;
+    if (d->timed_out) return fail_dist(d->ctx, "this communicator was abandoned after a time-out");
     struct Job { int st = C2D_OK; std::string error; };
     auto job = std::make_shared<Job>();
     const int device = d->ctx->device;
-    const bool in_time = run_with_deadline([d, stream, device, job]() {
+#ifdef C2D_DIST_REHEARSAL
+    c2d_ctx* ctx = d->ctx;
+#endif
+    const bool in_time = run_with_deadline([=]() {
         if (hipSetDevice(device) != hipSuccess) { job->st = C2D_ERR_HIP; job->error = "hipSetDevice failed on the barrier thread"; return; }
         unsigned long long* w = nullptr;
         if (hipMalloc(&w, sizeof *w) != hipSuccess) { job->st = C2D_ERR_NOMEM; job->error = "barrier word allocation failed"; return; }
-        if (hipMemsetAsync(w, 0, sizeof *w, (hipStream_t)stream) != hipSuccess) job->st = C2D_ERR_HIP;
+        if (hipMemsetAsync(w, 0, sizeof *w, (hipStream_t)stream) != hipSuccess) { job->st = C2D_ERR_HIP; job->error = "hipMemsetAsync failed in the barrier"; }
         if (job->st == C2D_OK) {
-            job->st = c2d_dist_all_reduce_sum_u64(d, w, 1, stream);
-            if (job->st != C2D_OK) job->error = d->ctx->last_error;
+#ifdef C2D_DIST_REHEARSAL
+            job->st = c2d_dist_all_reduce_sum_u64(d, w, 1, stream);  // (the file transport runs on the caller's side of the deadline anyway)
+            if (job->st != C2D_OK) job->error = ctx->last_error;
+#else
+            const ncclResult_t st = rccl().AllReduce(w, w, 1, ncclUint64, ncclSum, d->comm, (hipStream_t)stream);
+            if (st != ncclSuccess) { job->st = C2D_ERR_DIST; job->error = std::string("ncclAllReduce failed: ") + rccl().GetErrorString(st); }
+#endif
         }
         if (job->st == C2D_OK && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) { job->st = C2D_ERR_HIP; job->error = "hipStreamSynchronize failed in the barrier"; }
         (void)hipFree(w);
+#ifdef C2D_DIST_REHEARSAL
+    }, d->timeout_s + 10.0);  // (the file transport has this limit built in: let it report its own time-out)
+#else
     }, d->timeout_s);
+#endif
     if (!in_time) {
+        d->timed_out = true;
         char msg[160];
         std::snprintf(msg, sizeof msg, "rank %d: barrier did not complete within %.0f s (a peer is missing or stuck)", d->rank, d->timeout_s);
         return fail_dist(d->ctx, msg);
@@ -390,9 +409,35 @@ int c2d_dist_barrier(c2d_dist* d, c2d_stream stream)
     return job->st;
 }
 
+// hipStreamSynchronize under the same watchdog, for the collectives a caller has queued itself (c2d_dist_all_reduce_sum_u64 /
+// c2d_dist_broadcast_u64 are asynchronous): a peer that died after the communicator was built would otherwise hold the wait
+// for ever.
+int c2d_dist_stream_synchronize(c2d_dist* d, c2d_stream stream)
+{
+    if (!d) return C2D_ERR_INVALID_ARG;
+    if (d->timed_out) return fail_dist(d->ctx, "this communicator was abandoned after a time-out");
+    struct Job { int st = C2D_OK; };
+    auto job = std::make_shared<Job>();
+    const int device = d->ctx->device;
+    const bool in_time = run_with_deadline([=]() {
+        if (hipSetDevice(device) != hipSuccess || hipStreamSynchronize((hipStream_t)stream) != hipSuccess) job->st = C2D_ERR_HIP;
+    }, d->timeout_s);
+    if (!in_time) {
+        d->timed_out = true;
+        char msg[160];
+        std::snprintf(msg, sizeof msg, "rank %d: a collective did not complete within %.0f s (a peer is missing or stuck)", d->rank, d->timeout_s);
+        return fail_dist(d->ctx, msg);
+    }
+    if (job->st != C2D_OK) return fail_dist(d->ctx, "hipStreamSynchronize failed behind a collective", C2D_ERR_HIP);
+    return c2d_ctx_check_async(d->ctx);
+}
+
+int c2d_dist_timed_out(const c2d_dist* d) { return d && d->timed_out ? 1 : 0; }
+
 int c2d_dist_destroy(c2d_dist* d)
 {
     if (!d) return C2D_OK;
+    if (d->timed_out) return C2D_OK;  // a helper thread still holds it: left alone (the process is about to end)
 #ifdef C2D_DIST_REHEARSAL
     // own exchange files of the last two sequence numbers may remain; the peers are past reading them
     // once they have entered destroy too, which a final barrier establishes

@@ -887,8 +887,7 @@ int c2d_poly_bins_create(c2d_ctx* ctx, const c2d_poly_bin* bins, size_t n_bins, 
         else if (s.n && (!s.d_ax || !s.d_ay || !s.d_bx || !s.d_by || !s.d_out)) why = "c2d_poly_bins_create: NULL plane or result pointer";
         else if ((s.d_ka == nullptr) != (s.d_kb == nullptr)) why = "c2d_poly_bins_create: d_ka and d_kb must both be given or both be NULL";
         if (why) { release(B); return fail_arg(ctx, why); }
-        if (s.n == 0) continue;  // empty bins take no tiles
-        B->bins.push_back(s);
+        B->bins.push_back(s);  // (an empty bin stays in the list — c2d_poly_bins_get(i) is the caller's bin i — and takes no tiles)
         B->strides.push_back((uint32_t)(s.stride ? s.stride : s.n));
     }
     DeviceGuard g(ctx->device);

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -23,12 +24,22 @@ namespace fs = std::filesystem;
 
 // Error convention of the drivers: print and leave main with EXIT_FAILURE (the
 // reference's CUDA_CALL, utils.cu:70-72); the library itself never exits.
+// C2D_ERR_DIST is the exception: it may come from the watchdog of the aggregation link, which has then left a helper
+// thread inside RCCL / HIP (include/c2d.h).  A return from main would run exit(): static destructors and the HIP / ROCr
+// teardown would race that thread and can hang — defeating the watchdog.  So: report, flush, and end at once.
+[[noreturn]] inline void c2d_die_now()
+{
+    std::fflush(stdout);
+    std::fflush(stderr);
+    _exit(EXIT_FAILURE);
+}
 #define C2D_CALL(ctx, x)                                                                         \
     do {                                                                                         \
         int st__ = (x);                                                                          \
         if (st__ != C2D_OK) {                                                                    \
             std::fprintf(stderr, "Error at %s:%d: %s: %s (%s)\n", __FILE__, __LINE__, #x,        \
                          c2d_status_string(st__), (ctx) ? c2d_last_error(ctx) : "");            \
+            if (st__ == C2D_ERR_DIST) c2d_die_now();                                             \
             return EXIT_FAILURE;                                                                 \
         }                                                                                        \
     } while (0)
@@ -111,7 +122,8 @@ struct DistLink {
         ctx = c;
         if (sh.world <= 1 && sh.id_file.empty()) return C2D_OK;
         if (sh.id_file.empty()) return C2D_OK;  // externally launched without an id file: no aggregation (each rank reports itself)
-        int st = c2d_dist_init_file(ctx, sh.rank, sh.world, sh.id_file.c_str(), 300.0, &dist);
+        // 0 = the library's default limit: $C2D_DIST_TIMEOUT_S, or 300 s
+        int st = c2d_dist_init_file(ctx, sh.rank, sh.world, sh.id_file.c_str(), 0.0, &dist);
         if (st != C2D_OK) return st;
         return c2d_malloc(ctx, reinterpret_cast<void**>(&d_buf), kWords * sizeof(unsigned long long));
     }
@@ -124,7 +136,7 @@ struct DistLink {
         int st = c2d_memcpy_h2d(ctx, d_buf, h, count * sizeof *h, stream);
         if (st == C2D_OK) st = c2d_dist_all_reduce_sum_u64(dist, d_buf, count, stream);
         if (st == C2D_OK) st = c2d_memcpy_d2h(ctx, h, d_buf, count * sizeof *h, stream);
-        if (st == C2D_OK) st = c2d_stream_synchronize(ctx, stream);
+        if (st == C2D_OK) st = c2d_dist_stream_synchronize(dist, stream);  // (under the watchdog: a peer may have died since the link was built)
         return st;
     }
     // rank 0's values to everyone
@@ -135,7 +147,7 @@ struct DistLink {
         int st = c2d_memcpy_h2d(ctx, d_buf, h, count * sizeof *h, stream);
         if (st == C2D_OK) st = c2d_dist_broadcast_u64(dist, d_buf, count, 0, stream);
         if (st == C2D_OK) st = c2d_memcpy_d2h(ctx, h, d_buf, count * sizeof *h, stream);
-        if (st == C2D_OK) st = c2d_stream_synchronize(ctx, stream);
+        if (st == C2D_OK) st = c2d_dist_stream_synchronize(dist, stream);
         return st;
     }
     void close()
@@ -195,71 +207,6 @@ struct BatchSlot {
         ctx = nullptr;
     }
 };
-
-// ---- the reference's tables, drawn in parallel ---------------------------------------------------------------------
-// generate_dataset.cu:279-332 fills the variance and pose tables from ONE std::default_random_engine (minstd_rand0:
-// x <- 16807 x mod 2^31 - 1, default seed 1), row by row, dimension by dimension; uniform_real_distribution<float> takes
-// one engine call per float (generate_canonical<float, 24> needs 24 bits, the engine delivers ~31).  That engine can jump:
-// the state after k calls is 16807^k x mod (2^31 - 1).  Thread t therefore starts its slice of the table from the state
-// the serial loop would have there and draws the same floats — the 64^4-row default tables (134 M draws) in 1/T of the
-// serial 0.63 s.  The one-call-per-float property is libstdc++'s, not the standard's, so it is checked against a short
-// serial run first; if it does not hold the table is drawn serially.
-inline uint64_t minstd_power(uint64_t k)
-{
-    const uint64_t m = 2147483647ull;
-    uint64_t result = 1, base = 16807;
-    for (; k; k >>= 1) {
-        if (k & 1) result = result * base % m;
-        base = base * base % m;
-    }
-    return result;
-}
-
-// rows x dims floats, dimension d uniform in [lo[d], hi[d]); first_draw = engine calls made before this table
-inline void fill_uniform_table_serial(float* out, size_t rows, int dims, const float* lo, const float* hi, std::minstd_rand0& gen)
-{
-    std::vector<std::uniform_real_distribution<float>> u;
-    for (int d = 0; d < dims; d++) u.emplace_back(lo[d], hi[d]);
-    for (size_t i = 0; i < rows; i++)
-        for (int d = 0; d < dims; d++) out[i * dims + d] = u[d](gen);
-}
-
-inline bool fill_uniform_table(float* out, size_t rows, int dims, const float* lo, const float* hi, uint64_t first_draw, unsigned threads)
-{
-    auto engine_at = [](uint64_t calls) {
-        std::minstd_rand0 e;  // default seed 1
-        e.seed(static_cast<std::minstd_rand0::result_type>(minstd_power(calls)));
-        return e;
-    };
-    // does a jumped engine continue the serial sequence on this standard library?  (one engine call per float)
-    {
-        const size_t probe = 64;
-        std::vector<float> a(probe * dims), b(probe * dims);
-        std::minstd_rand0 serial = engine_at(0);
-        fill_uniform_table_serial(a.data(), probe, dims, lo, hi, serial);
-        std::minstd_rand0 j0 = engine_at(0), j1 = engine_at(probe / 2 * dims);
-        fill_uniform_table_serial(b.data(), probe / 2, dims, lo, hi, j0);
-        fill_uniform_table_serial(b.data() + probe / 2 * dims, probe / 2, dims, lo, hi, j1);
-        if (a != b) threads = 1;
-    }
-    if (threads <= 1 || rows < 4096) {
-        std::minstd_rand0 e = engine_at(first_draw);
-        fill_uniform_table_serial(out, rows, dims, lo, hi, e);
-        return threads > 1;
-    }
-    std::vector<std::thread> pool;
-    const size_t per = (rows + threads - 1) / threads;
-    for (unsigned t = 0; t < threads; t++) {
-        const size_t b = t * per, e = b + per < rows ? b + per : rows;
-        if (b >= e) break;
-        pool.emplace_back([=]() {
-            std::minstd_rand0 eng = engine_at(first_draw + b * dims);
-            fill_uniform_table_serial(out + b * dims, e - b, dims, lo, hi, eng);
-        });
-    }
-    for (auto& th : pool) th.join();
-    return true;
-}
 
 inline std::vector<StdDev> std_devs_from_variances(const std::vector<float>& var_flat)
 {

@@ -131,45 +131,57 @@ int main(int argc, char* argv[])
         return EXIT_FAILURE;
     }
 
-    // Tables.  Same generator, distributions and draw order as the reference
-    // (generate_dataset.cu:279-332): std::default_random_engine, default seeded, all variances
-    // first, then all poses — so a libstdc++ build reproduces the reference's tables.
-    std::vector<float> variances, poses;  // flat [Nv][5], [Np][3]
-    uint64_t draws = 0;  // engine calls so far (the serial std::default_random_engine of the reference, drawn in parallel: driver_common.hpp)
-    const unsigned table_threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
     PhaseClock clock;
-    double table_file_s = 0.0;
-    auto timed_save = [&](const std::string& path, std::vector<size_t> shape, const float* data) {
-        const auto t0 = std::chrono::steady_clock::now();
-        npy::save_f32(path, shape, data);
-        table_file_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    };
+    const size_t B = static_cast<size_t>(a.batch_size);
+    BatchSlot slots[2];
+    for (auto& sl : slots) C2D_CALL(sl.ctx, sl.open(shard.device, B));
+    c2d_ctx* ctx = slots[0].ctx;          // owner of the tables and of the aggregation link
+    c2d_stream stream = slots[0].stream;
+    clock.lap("device_open");
+    DistLink link;
+    C2D_CALL(ctx, link.open(ctx, shard));
+    if (link.active()) {  // rank 0's seed is everyone's
+        unsigned long long w[1] = {a.seed};
+        C2D_CALL(ctx, link.broadcast(w, 1, stream));
+        a.seed = w[0];
+    }
+    if (chatty) std::cout << "seed: " << a.seed << std::endl;
+
+    // Tables.  Same generator, distributions and draw order as the reference (generate_dataset.cu:279-332):
+    // std::default_random_engine, default seeded, all variances first, then all poses — drawn ON THE DEVICE
+    // (c2d_uniform_table_minstd: the engine can jump, every lane starts at its own draw), bit-identical to a libstdc++
+    // run of the reference's serial loop.  Nothing is drawn or uploaded per rank on the host; rank 0 saves the two
+    // tables (:300-332) from a download that runs beside the batches.
+    void *d_var = nullptr, *d_poses = nullptr, *d_sd = nullptr;
+    bool var_made = false, poses_made = false;
     try {
         if (a.variance_dir.empty()) {
             if (!a.shape_variance) {
                 a.min_variance[3] = a.max_variance[3] = 0.0f;
                 a.min_variance[4] = a.max_variance[4] = 0.0f;
             }
-            variances.resize(static_cast<size_t>(a.num_variances) * 5);
-            fill_uniform_table(variances.data(), static_cast<size_t>(a.num_variances), 5, a.min_variance.data(), a.max_variance.data(), draws, table_threads);
-            draws += static_cast<uint64_t>(a.num_variances) * 5;
-            if (shard.rank == 0) timed_save(data_dir + "/variances.npy", {static_cast<size_t>(a.num_variances), 5}, variances.data());
+            var_made = true;
         } else {
             npy::Array v = npy::load_f32(a.variance_dir);
             if (v.data.size() % 5) throw std::runtime_error("variances file is not [N,5]");
-            variances = std::move(v.data);
-            a.num_variances = static_cast<int>(variances.size() / 5);
+            a.num_variances = static_cast<int>(v.data.size() / 5);
+            if (a.num_variances > 0) {
+                C2D_CALL(ctx, c2d_malloc(ctx, &d_var, v.data.size() * sizeof(float)));
+                C2D_CALL(ctx, c2d_memcpy_h2d(ctx, d_var, v.data.data(), v.data.size() * sizeof(float), stream));
+                C2D_CALL(ctx, c2d_stream_synchronize(ctx, stream));  // (the host array is a local)
+            }
         }
         if (a.pose_dir.empty()) {
-            poses.resize(static_cast<size_t>(a.num_poses) * 3);
-            fill_uniform_table(poses.data(), static_cast<size_t>(a.num_poses), 3, a.min_pose.data(), a.max_pose.data(), draws, table_threads);
-            draws += static_cast<uint64_t>(a.num_poses) * 3;
-            if (shard.rank == 0) timed_save(data_dir + "/poses.npy", {static_cast<size_t>(a.num_poses), 3}, poses.data());
+            poses_made = true;
         } else {
             npy::Array v = npy::load_f32(a.pose_dir);
             if (v.data.size() % 3) throw std::runtime_error("poses file is not [N,3]");
-            poses = std::move(v.data);
-            a.num_poses = static_cast<int>(poses.size() / 3);
+            a.num_poses = static_cast<int>(v.data.size() / 3);
+            if (a.num_poses > 0) {
+                C2D_CALL(ctx, c2d_malloc(ctx, &d_poses, v.data.size() * sizeof(float)));
+                C2D_CALL(ctx, c2d_memcpy_h2d(ctx, d_poses, v.data.data(), v.data.size() * sizeof(float), stream));
+                C2D_CALL(ctx, c2d_stream_synchronize(ctx, stream));
+            }
         }
         if (shard.rank == 0) {
             npy::save_f32(data_dir + "/meta/accuracy_bins.npy", {a.accuracy_bins.size()}, a.accuracy_bins.data());
@@ -180,36 +192,57 @@ int main(int argc, char* argv[])
         return EXIT_FAILURE;
     }
     if (a.num_poses <= 0 || a.num_variances <= 0) { std::cerr << "error: empty pose / variance table\n"; return EXIT_FAILURE; }
-    std::vector<StdDev> std_devs = std_devs_from_variances(variances);
-    clock.lap("tables_generate_and_save");
-    clock.phases.back().second -= table_file_s;
-    clock.phases.back().first = "tables_generate";
-    clock.add("tables_save_npy", table_file_s);
+    const size_t nv = static_cast<size_t>(a.num_variances), np_ = static_cast<size_t>(a.num_poses);
+    if (var_made) {
+        C2D_CALL(ctx, c2d_malloc(ctx, &d_var, nv * 5 * sizeof(float)));
+        C2D_CALL(ctx, c2d_uniform_table_minstd(ctx, static_cast<float*>(d_var), nv, 5, a.min_variance.data(), a.max_variance.data(), 0, stream));
+    }
+    if (poses_made) {
+        C2D_CALL(ctx, c2d_malloc(ctx, &d_poses, np_ * 3 * sizeof(float)));
+        // the engine has made 5 * num_variances calls when the pose loop starts — only if the variance loop ran (:282, :321)
+        C2D_CALL(ctx, c2d_uniform_table_minstd(ctx, static_cast<float*>(d_poses), np_, 3, a.min_pose.data(), a.max_pose.data(), var_made ? nv * 5 : 0, stream));
+    }
+    C2D_CALL(ctx, c2d_malloc(ctx, &d_sd, nv * sizeof(StdDev)));
+    C2D_CALL(ctx, c2d_sqrt_f32(ctx, static_cast<const float*>(d_var), static_cast<float*>(d_sd), nv * 5, stream));  // :309-317
+    C2D_CALL(ctx, c2d_stream_synchronize(ctx, stream));
+    clock.lap("tables_on_device");
+    // rank 0 saves the generated tables: its own thread, ctx and stream, page-locked staging, beside the batches
+    double table_save_s = 0.0;
+    std::string table_save_error;
+    std::thread table_saver;
+    struct JoinOnExit { std::thread& t; ~JoinOnExit() { if (t.joinable()) t.join(); } } join_saver{table_saver};  // (every return path)
+    if (shard.rank == 0 && (var_made || poses_made)) {
+        table_saver = std::thread([&, nv, np_]() {
+            const auto t0 = std::chrono::steady_clock::now();
+            c2d_ctx* c2 = nullptr;
+            c2d_stream s2 = nullptr;
+            void* h = nullptr;
+            auto step = [&](int st, const char* what) {
+                if (st != C2D_OK && table_save_error.empty()) table_save_error = std::string(what) + ": " + (c2 ? c2d_last_error(c2) : c2d_status_string(st));
+                return st == C2D_OK;
+            };
+            try {
+                const size_t floats = std::max(var_made ? nv * 5 : 0, poses_made ? np_ * 3 : 0);
+                if (step(c2d_ctx_create(shard.device, &c2), "c2d_ctx_create") && step(c2d_stream_create(c2, &s2), "c2d_stream_create") &&
+                    step(c2d_malloc_host(c2, &h, floats * sizeof(float)), "c2d_malloc_host")) {
+                    if (var_made && step(c2d_memcpy_d2h(c2, h, d_var, nv * 5 * sizeof(float), s2), "download") && step(c2d_stream_synchronize(c2, s2), "download"))
+                        npy::save_f32(data_dir + "/variances.npy", {nv, 5}, static_cast<const float*>(h));
+                    if (poses_made && step(c2d_memcpy_d2h(c2, h, d_poses, np_ * 3 * sizeof(float), s2), "download") && step(c2d_stream_synchronize(c2, s2), "download"))
+                        npy::save_f32(data_dir + "/poses.npy", {np_, 3}, static_cast<const float*>(h));
+                }
+            } catch (const std::exception& e) {
+                if (table_save_error.empty()) table_save_error = e.what();
+            }
+            if (h) c2d_free_host(c2, h);
+            if (s2) c2d_stream_destroy(c2, s2);
+            if (c2) c2d_ctx_destroy(c2);
+            table_save_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        });
+    }
     if (chatty) {
         std::cout << "num poses: " << a.num_poses << std::endl;
         std::cout << "num variances: " << a.num_variances << std::endl;
     }
-
-    const size_t B = static_cast<size_t>(a.batch_size);
-    BatchSlot slots[2];
-    for (auto& sl : slots) C2D_CALL(sl.ctx, sl.open(shard.device, B));
-    c2d_ctx* ctx = slots[0].ctx;          // owner of the tables and of the aggregation link
-    c2d_stream stream = slots[0].stream;
-    DistLink link;
-    C2D_CALL(ctx, link.open(ctx, shard));
-    if (link.active()) {  // rank 0's seed is everyone's
-        unsigned long long w[1] = {a.seed};
-        C2D_CALL(ctx, link.broadcast(w, 1, stream));
-        a.seed = w[0];
-    }
-    if (chatty) std::cout << "seed: " << a.seed << std::endl;
-    void *d_poses = nullptr, *d_sd = nullptr;
-    C2D_CALL(ctx, c2d_malloc(ctx, &d_poses, poses.size() * sizeof(float)));
-    C2D_CALL(ctx, c2d_malloc(ctx, &d_sd, std_devs.size() * sizeof(StdDev)));
-    C2D_CALL(ctx, c2d_memcpy_h2d(ctx, d_poses, poses.data(), poses.size() * sizeof(float), stream));
-    C2D_CALL(ctx, c2d_memcpy_h2d(ctx, d_sd, std_devs.data(), std_devs.size() * sizeof(StdDev), stream));
-    C2D_CALL(ctx, c2d_stream_synchronize(ctx, stream));
-    clock.lap("device_open_and_table_upload");
     double wait_gpu_s = 0.0, host_batch_s = 0.0;  // inside the batch loop: waiting for a batch's stream / statistics + shuffle + file
 
     const auto begin = std::chrono::steady_clock::now();
@@ -292,10 +325,16 @@ int main(int argc, char* argv[])
         std::cout << "Elapsed time: " << std::chrono::duration_cast<std::chrono::minutes>(end - begin).count() << " [min]" << std::endl;
     }
     clock.lap("batches");
+    if (table_saver.joinable()) {
+        table_saver.join();
+        clock.lap("tables_save_npy_after_the_batches");
+        clock.add("tables_save_npy_thread", table_save_s);
+        if (!table_save_error.empty()) { std::cerr << "error: saving the tables: " << table_save_error << "\n"; return EXIT_FAILURE; }
+    }
     clock.add("batches_waiting_for_gpu", wait_gpu_s);
     clock.add("batches_host_stats_shuffle_npy", host_batch_s);
     C2D_CALL(ctx, print_json_summary("generate_dataset", shard, stats, counter, &link, stream, clock.json()));
-    for (void* ptr : {d_poses, d_sd}) c2d_free(ctx, ptr);
+    for (void* ptr : {d_var, d_poses, d_sd}) c2d_free(ctx, ptr);
     link.close();
     for (auto& sl : slots) sl.close();
     if (chatty) std::cout << "Done." << std::endl;

@@ -440,6 +440,20 @@ typedef struct c2d_mc_poly_scenes_args {
 } c2d_mc_poly_scenes_args;
 int c2d_mc_poly_scenes(c2d_ctx* ctx, const c2d_mc_poly_scenes_args* args, c2d_stream stream);
 
+/* ---- the dataset's tables -------------------------------------------------------
+ * c2d_uniform_table_minstd: the table fill of generate_dataset.cu:279-332 on the device.  The reference
+ * draws its variance and pose tables on the host from ONE std::default_random_engine (minstd_rand0,
+ * default seed), row by row, dimension d uniform in [lo[d], hi[d]) through
+ * std::uniform_real_distribution<float>, and uploads them; this writes d_out[rows][dims] with exactly those
+ * floats (libstdc++'s: one engine call per float, value = float(x - 1) * 2^-31 * (hi - lo) + lo), engine
+ * calls first_draw .. first_draw + rows * dims - 1 of that engine — the variances first (first_draw = 0),
+ * then the poses (first_draw = 5 * num_variances), as the reference.  lo, hi: host float[dims], dims <= 8.
+ * c2d_sqrt_f32: element-wise correctly rounded square root, d_out[i] = sqrt(d_in[i]) — the standard
+ * deviations of the variance table (generate_dataset.cu:309-317, compute_collision_probability.cu:188-194). */
+int c2d_uniform_table_minstd(c2d_ctx* ctx, float* d_out, size_t rows, int dims, const float* lo, const float* hi,
+                             uint64_t first_draw, c2d_stream stream);
+int c2d_sqrt_f32(c2d_ctx* ctx, const float* d_in, float* d_out, size_t n, c2d_stream stream);
+
 /* ---- multi-GPU aggregation ----------------------------------------------------
  * New work (the reference is single-GPU, compute_collision_probability.cu:212-251): pairs,
  * scenes and Monte-Carlo sample ranges shard over the GPUs of a node with no exchange on
@@ -460,11 +474,16 @@ int c2d_mc_poly_scenes(c2d_ctx* ctx, const c2d_mc_poly_scenes_args* args, c2d_st
  *                        asynchronous on `stream` like every other entry point;
  *   c2d_dist_barrier   : a one-word all-reduce followed by a stream synchronise.
  *
- * c2d_dist_init and c2d_dist_barrier (hence c2d_dist_init_file) run under a watchdog: if the
- * peers do not arrive within the time limit (timeout_s of c2d_dist_init_file; $C2D_DIST_TIMEOUT_S
- * or 300 s for c2d_dist_init) they return C2D_ERR_DIST instead of blocking for ever; the process
- * should then report the error and end (a helper thread is left inside RCCL: after such a
- * time-out the communicator must neither be used nor destroyed).
+ * c2d_dist_init, c2d_dist_barrier (hence c2d_dist_init_file) and c2d_dist_stream_synchronize run
+ * under a watchdog: if the peers do not arrive within the time limit (timeout_s of
+ * c2d_dist_init_file, 0 = the default; $C2D_DIST_TIMEOUT_S or 300 s otherwise) they return
+ * C2D_ERR_DIST instead of blocking for ever.  A helper thread is then left inside RCCL / HIP:
+ * c2d_dist_timed_out() says so, the communicator refuses further use, c2d_dist_destroy leaves it
+ * alone, and the process should report the error and end with _exit() — the runtime's teardown in
+ * a normal exit() would race that thread (the drivers do exactly this).
+ * c2d_dist_all_reduce_sum_u64 / c2d_dist_broadcast_u64 only ENQUEUE; a caller that waits for them
+ * with c2d_stream_synchronize blocks for ever if a peer died after the communicator was built —
+ * c2d_dist_stream_synchronize is the same wait under the watchdog.
  *
  * c2d_dist_transport() names the transport: "rccl" — the only one this library contains.  A
  * separate test build (lib-rehearsal/libc2d.so, `make lib-rehearsal`) replaces it by a sum
@@ -484,6 +503,8 @@ int c2d_dist_all_reduce_sum_u64(c2d_dist* dist, unsigned long long* d_buf, size_
 int c2d_dist_broadcast_u64(c2d_dist* dist, unsigned long long* d_buf, size_t count, int root,
                            c2d_stream stream);
 int c2d_dist_barrier(c2d_dist* dist, c2d_stream stream);
+int c2d_dist_stream_synchronize(c2d_dist* dist, c2d_stream stream);
+int c2d_dist_timed_out(const c2d_dist* dist); /* 1 after a watchdog time-out on this communicator */
 int c2d_dist_destroy(c2d_dist* dist);
 
 /* Host-side helpers with the reference's semantics, exported so that callers

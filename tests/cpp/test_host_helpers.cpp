@@ -103,33 +103,6 @@ static int test_common(const std::string& dir)
     return 0;
 }
 
-// the tables drawn by several threads from jumped engines equal the reference's serial loop over ONE default engine
-static int test_tables()
-{
-    const float lo5[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, hi5[5] = {0.3f, 0.3f, 0.3f, 0.f, 0.f};
-    const float lo3[3] = {0.1f, 0.1f, 0.f}, hi3[3] = {5.f, 5.f, 6.2831853f};
-    for (size_t nv : {size_t(1), size_t(77), size_t(5000), size_t(70001)}) {
-        const size_t np_ = nv + 13;
-        std::vector<float> ref_v(nv * 5), ref_p(np_ * 3), v(nv * 5), p(np_ * 3);
-        std::default_random_engine gen;  // generate_dataset.cu:280
-        {
-            std::vector<std::uniform_real_distribution<float>> u;
-            for (int d = 0; d < 5; d++) u.emplace_back(lo5[d], hi5[d]);
-            for (size_t i = 0; i < nv; i++) for (int d = 0; d < 5; d++) ref_v[i * 5 + d] = u[d](gen);
-            std::vector<std::uniform_real_distribution<float>> w;
-            for (int d = 0; d < 3; d++) w.emplace_back(lo3[d], hi3[d]);
-            for (size_t i = 0; i < np_; i++) for (int d = 0; d < 3; d++) ref_p[i * 3 + d] = w[d](gen);
-        }
-        for (unsigned threads : {1u, 3u, 8u}) {
-            fill_uniform_table(v.data(), nv, 5, lo5, hi5, 0, threads);
-            fill_uniform_table(p.data(), np_, 3, lo3, hi3, nv * 5, threads);
-            CHECK(v == ref_v && p == ref_p);
-        }
-    }
-    CHECK(minstd_power(0) == 1 && minstd_power(1) == 16807 && minstd_power(2) == 282475249ull);
-    return 0;
-}
-
 int main(int argc, char** argv)
 {
     if (argc < 2) return 2;
@@ -137,7 +110,6 @@ int main(int argc, char** argv)
     if (test_npy(dir)) return 1;
     if (test_cli()) return 1;
     if (test_common(dir)) return 1;
-    if (test_tables()) return 1;
     std::puts("host helpers ok");
     return 0;
 }

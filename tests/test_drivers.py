@@ -67,12 +67,22 @@ def test_self_launched_ranks_propagate_failure_without_gpu(tmp_path):
 
 
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="CPU-only behaviour")
-def test_generate_dataset_writes_tables_then_fails_loudly_without_gpu(tmp_path):
+def test_generate_dataset_fails_loudly_without_gpu(tmp_path):
+    """no CPU fallback anywhere: since round 4 even the tables are drawn on the device (c2d_uniform_table_minstd), so without a GPU
+    the driver stops at c2d_ctx_create and writes no table"""
     d = tmp_path / "data"
-    out = run([GEN, "--data_dir", str(d), "-n", "1", "-b", "100", "--num_poses", "1000", "--num_variances", "500",
+    out = run([GEN, "--data_dir", str(d), "-n", "1", "-b", "100", "--num_poses", "1000", "--num_variances", "500"])
+    assert out.returncode != 0 and "no usable device" in out.stderr
+    assert not (d / "poses.npy").exists() and not (d / "variances.npy").exists()
+
+
+@pytest.mark.gpu
+def test_generate_dataset_tables_and_meta_files(tmp_path):
+    d = tmp_path / "data"
+    out = run([GEN, "--data_dir", str(d), "-n", "1", "-b", "100", "--num_poses", "1000", "--num_variances", "500", "--max_samples", "2000",
                "--min_pose", "0.5", "0.25", "0", "--max_pose", "2", "3", "1", "--accuracy_bins", "0", "0.5", "1",
-               "--bin_accuracy", "0.01", "0.02"])
-    assert out.returncode != 0 and "no usable device" in out.stderr   # no CPU fallback
+               "--bin_accuracy", "0.01", "0.02", "--seed", "1"])
+    assert out.returncode == 0, out.stderr
     poses = np.load(d / "poses.npy")
     var = np.load(d / "variances.npy")
     assert poses.shape == (1000, 3) and poses.dtype == np.float32
@@ -82,6 +92,28 @@ def test_generate_dataset_writes_tables_then_fails_loudly_without_gpu(tmp_path):
     assert (var[:, 3:] == 0).all()                                      # shape_variance off (generate_dataset.cu:285-290)
     assert np.load(d / "meta" / "accuracy_bins.npy").tolist() == [0, 0.5, 1]
     assert np.allclose(np.load(d / "meta" / "bin_accuracy.npy"), [0.01, 0.02])
+    # the first values of libstdc++'s default engine through uniform_real_distribution<float>(0, 0.3): 16807, 16807^2 mod M, ...
+    M = 2147483647
+    x, want = 1, []
+    for _ in range(3):
+        x = x * 16807 % M
+        want.append(np.float32(np.float32(x - 1) * np.float32(2.0 ** -31)) * np.float32(0.3))
+    assert var[0, :3].tolist() == [float(w) for w in want]
+    summary = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert "tables_on_device" in summary["phases_s"] and "tables_save_npy_thread" in summary["phases_s"]
+
+
+@pytest.mark.gpu
+def test_device_tables_equal_the_reference_loop(tmp_path):
+    """c2d_uniform_table_minstd / c2d_sqrt_f32 against std::default_random_engine + uniform_real_distribution<float> (the reference's own
+    loop, generate_dataset.cu:279-332), bit for bit: small and odd sizes, and the reference's default 64^4 rows per table"""
+    exe = tmp_path / "test_device_tables"
+    lib = os.path.join(ROOT, "convex-2d-gpu-collision-detection_amd", "lib")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", os.path.join(ROOT, "tests", "cpp", "test_device_tables.cpp"), "-o", str(exe),
+                    "-L" + lib, "-lc2d", "-Wl,-rpath," + lib, "-Wl,-rpath-link,/opt/rocm/lib"], check=True)
+    for nv, np_, shape in [(1, 1, 0), (77, 90, 1), (70001, 5003, 0), (64 ** 4, 64 ** 4, 0)]:
+        out = subprocess.run([str(exe), str(nv), str(np_), str(shape)], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and " 0 differing floats" in out.stdout, out.stdout + out.stderr
 
 
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="CPU-only behaviour")

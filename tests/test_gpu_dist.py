@@ -50,6 +50,9 @@ def test_c2d_dist_rccl_single_rank(eng, pkg, tmp_path):
     d.all_reduce_sum_u64(buf, 3)
     d.broadcast_u64(buf, 3, root=0)
     d.barrier()
+    d.all_reduce_sum_u64(buf, 3)
+    d.synchronize()                     # the watched wait for queued collectives
+    assert not d.timed_out
     assert buf.get().tolist() == [5, 2**40 + 7, 0]
     d.close()
     path = str(tmp_path / "id")
@@ -237,6 +240,59 @@ def test_watchdog_times_out_instead_of_hanging(eng, pkg):
         "sys.stdout.flush(); os._exit(0)\n" % ROOT)
     out = run([sys.executable, "-c", code])
     assert "STATUS -6" in out.stdout and "did not complete within 4 s" in out.stdout, out.stdout + out.stderr
+
+
+def test_driver_ends_at_once_when_a_peer_never_arrives(tmp_path):
+    """a driver whose peer never shows up must report C2D_ERR_DIST and END — not return through exit(), whose HIP
+    teardown would race the helper thread the watchdog left inside RCCL.  Product library, real RCCL: rank 0 of a world of two,
+    rank 1 never started, $C2D_DIST_TIMEOUT_S = 4 (the drivers pass 0 = "the default" to c2d_dist_init_file, so the variable
+    applies to them).  Both modes of the driver that open a link."""
+    import time
+
+    env = {"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0", "C2D_DIST_TIMEOUT_S": "4"}
+    for k, extra in enumerate((["--pair_samples", "100000", "--seed", "1"], None)):
+        e = dict(env, C2D_DIST_ID_FILE=str(tmp_path / f"id{k}"))
+        if extra is None:  # dataset mode needs its directories to exist before it opens the link
+            (tmp_path / "in").mkdir()
+            (tmp_path / "out" / "meta").mkdir(parents=True)
+            np.save(tmp_path / "in" / "0.npy", np.zeros((4, 4), np.float32))
+            np.save(tmp_path / "out" / "poses.npy", np.ones((2, 3), np.float32))
+            np.save(tmp_path / "out" / "variances.npy", np.ones((2, 5), np.float32) * 0.1)
+            np.save(tmp_path / "out" / "meta" / "accuracy_bins.npy", np.array([0, .01, .1, 1], np.float32))
+            np.save(tmp_path / "out" / "meta" / "bin_accuracy.npy", np.array([1e-4, 1e-3, 1e-2], np.float32))
+            extra = ["--data_in", str(tmp_path / "in"), "--data_out", str(tmp_path / "out"), "--seed", "2"]
+        t0 = time.time()
+        out = subprocess.run([CCP] + extra, capture_output=True, text=True, timeout=120, env=dict(os.environ, **e))
+        took = time.time() - t0
+        assert out.returncode != 0, out.stdout + out.stderr
+        assert "did not complete within 4 s" in out.stderr, out.stderr
+        assert took < 60, took   # the 4-second limit plus start-up, not the 300-second default, and no hang in the teardown
+
+
+def test_peer_that_dies_after_the_link_was_built(tmp_path, pkg):
+    """c2d_dist_stream_synchronize / the drivers' DistLink::sum: the result collectives are under the deadline too.  Rehearsed with
+    the file transport: rank 1 joins the link and then dies before the reduce; rank 0 must fail within its limit."""
+    import time
+
+    code = (
+        "import os, sys, time; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from __graft_entry__ import load_package; pkg = load_package(); eng = pkg.Engine(0, lib_path=%r)\n"
+        "rank = int(sys.argv[1])\n"
+        "d = eng.dist_init_file(rank, 2, sys.argv[2], 3.0)\n"
+        "if rank == 1: os._exit(0)\n"
+        "buf = eng.to_device(np.array([1], np.uint64)); t0 = time.time()\n"
+        "try:\n"
+        "    d.all_reduce_sum_u64(buf, 1); d.synchronize(); print('NO ERROR')\n"
+        "except pkg.C2DError as e:\n"
+        "    print('STATUS', e.status, round(time.time() - t0, 1), str(e))\n"
+        "sys.stdout.flush(); os._exit(0)\n" % (ROOT, REH_LIB))
+    idf = str(tmp_path / "id")
+    p0 = subprocess.Popen([sys.executable, "-c", code, "0", idf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    p1 = subprocess.Popen([sys.executable, "-c", code, "1", idf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    o0, e0 = p0.communicate(timeout=120)
+    p1.communicate(timeout=120)
+    assert "STATUS -6" in o0 and "timed out" in o0, o0 + e0
 
 
 def test_rehearsal_transport_lives_in_its_own_build(eng, pkg):
