@@ -7,7 +7,7 @@ HIPCC    ?= /opt/rocm/bin/hipcc
 # -fno-slp-vectorize: hipcc otherwise packs scalar f32 ops into v_pk_mul/add_f32, measured 2 % slower here.
 HIPFLAGS := -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fPIC -Wall -Wextra -Wno-unused-parameter -Iinclude
 
-SRCS := $(CSRC)/c2d_api.hip $(CSRC)/c2d_sat.hip $(CSRC)/c2d_poly.hip $(CSRC)/c2d_poly_binned.hip $(CSRC)/c2d_mc.hip $(CSRC)/c2d_mc_poly.hip $(CSRC)/c2d_tables.hip $(CSRC)/c2d_dist.hip
+SRCS := $(CSRC)/c2d_api.hip $(CSRC)/c2d_host.hip $(CSRC)/c2d_sat.hip $(CSRC)/c2d_poly.hip $(CSRC)/c2d_poly_binned.hip $(CSRC)/c2d_mc.hip $(CSRC)/c2d_mc_poly.hip $(CSRC)/c2d_tables.hip $(CSRC)/c2d_dist.hip
 OBJS := $(SRCS:.hip=.o)
 HDRS := $(CSRC)/c2d_math.hpp $(CSRC)/c2d_mc_core.hpp $(CSRC)/c2d_count.hpp $(CSRC)/c2d_internal.hpp include/c2d.h include/utils.h
 

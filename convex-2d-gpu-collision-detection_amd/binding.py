@@ -133,6 +133,8 @@ _SIGNATURES = {
     "c2d_sat_rect_pairs_verts_mask": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "c2d_sat_rect_pairs_aos": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "c2d_sat_rect_pairs_pose": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "c2d_sat_rect_pairs_verts_host": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p, C.POINTER(C.c_ulonglong)]),
+    "c2d_sat_rect_pairs_pose_host": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p, C.POINTER(C.c_ulonglong)]),
     "c2d_sat_poly_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "c2d_sat_poly_pairs_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "c2d_poly_bins_create": (C.c_int, [C.c_void_p, C.POINTER(_PolyBin), C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -451,6 +453,37 @@ class Engine:
         arr = (C.c_void_p * 10)(*[_ptr_of(p) for p in planes])
         self._check(self.lib.c2d_sat_rect_pairs_pose(self.h, arr, n, _ptr_of(out), _ptr_of(count), C.c_void_p(stream)),
                     "c2d_sat_rect_pairs_pose")
+
+    def sat_rect_pairs_host(self, planes, out: np.ndarray, fmt: str = "verts") -> int:
+        """c2d_sat_rect_pairs_verts_host / _pose_host: planes = 16 (10) host pointers or 1-D float32 arrays of n elements each, out = host u8[n]
+        (numpy arrays or the arrays of host_empty()); returns the number of colliding pairs"""
+        want = 16 if fmt == "verts" else 10
+        if len(planes) != want:
+            raise ValueError("need %d planes" % want)
+        n = out.shape[0]
+        ptrs = [(p.ctypes.data if isinstance(p, np.ndarray) else int(p)) for p in planes]
+        arr = (C.c_void_p * want)(*ptrs)
+        cnt = C.c_ulonglong(0)
+        fn = self.lib.c2d_sat_rect_pairs_verts_host if fmt == "verts" else self.lib.c2d_sat_rect_pairs_pose_host
+        self._check(fn(self.h, arr, n, C.c_void_p(out.ctypes.data), C.byref(cnt)), "c2d_sat_rect_pairs_%s_host" % fmt)
+        return int(cnt.value)
+
+    def host_empty(self, shape, dtype) -> np.ndarray:
+        """a numpy array in page-locked host memory (c2d_malloc_host); free it with host_free(array)"""
+        dt = np.dtype(dtype)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
+        p = C.c_void_p()
+        self._check(self.lib.c2d_malloc_host(self.h, C.byref(p), max(nbytes, 1)), "c2d_malloc_host")
+        buf = (C.c_char * max(nbytes, 1)).from_address(p.value)
+        a = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[a.ctypes.data] = p.value
+        return a
+
+    def host_free(self, a: np.ndarray):
+        p = getattr(self, "_pinned", {}).pop(a.ctypes.data, None)
+        if p:
+            self._check(self.lib.c2d_free_host(self.h, C.c_void_p(p)), "c2d_free_host")
 
     def sat_poly_pairs_rows(self, vx, vy, k, n: int, rows: int, out, count=None, stream: int = 0):
         self._check(self.lib.c2d_sat_poly_pairs_rows(self.h, _ptr_of(vx), _ptr_of(vy), _ptr_of(k), n, rows, _ptr_of(out), _ptr_of(count),

@@ -77,6 +77,7 @@ int c2d_ctx_destroy(c2d_ctx* ctx)
     if (ctx->d_count_words2) (void)hipFree(ctx->d_count_words2);
     if (ctx->d_bins) (void)hipFree(ctx->d_bins);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    c2d_host_pipe_free(ctx->host_pipe);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->h_async_err) (void)hipHostFree(ctx->h_async_err);
     delete ctx;

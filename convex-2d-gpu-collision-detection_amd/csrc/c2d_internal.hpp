@@ -9,6 +9,9 @@
 
 #include "../../include/c2d.h"
 
+struct c2d_host_pipe;                              // stream and buffers of the host-resident entry points (c2d_host.hip)
+void c2d_host_pipe_free(c2d_host_pipe* p);
+
 struct c2d_ctx {
     int device = 0;
     hipDeviceProp_t prop{};
@@ -19,6 +22,7 @@ struct c2d_ctx {
     unsigned long long* d_count_words = nullptr;  // 256 x 128 B arrival/sum words of the SAT count (self-clearing)
     unsigned long long* d_count_words2 = nullptr; // two-level form for the polygon kernels (c2d_count.hpp), self-clearing
     float* d_bins = nullptr;                   // accuracy_bins | bin_accuracy (<= 32 floats)
+    c2d_host_pipe* host_pipe = nullptr;        // made at the first c2d_sat_rect_pairs_*_host call, kept
     void* d_scratch = nullptr;                 // grown on demand, kept: the binning pass's histograms and tables (c2d_poly_bins_from_padded)
     size_t scratch_bytes = 0;
     uint32_t* h_pinned = nullptr;              // pinned host word for count read-back

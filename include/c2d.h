@@ -173,6 +173,20 @@ int c2d_sat_rect_pairs_aos(c2d_ctx* ctx, const float* d_r1, const float* d_r2, s
 int c2d_sat_rect_pairs_pose(c2d_ctx* ctx, const float* const d_pose_planes[10], size_t n,
                             uint8_t* d_out, unsigned long long* d_count, c2d_stream stream);
 
+/* c2d_sat_rect_pairs_verts_host / _pose_host: the same tests for batches that live in HOST memory — what the
+ * reference does around its kernel with one blocking cudaMemcpy after the other
+ * (compute_collision_probability.cu:270-274 up, :314-318 down) — as ONE synchronous call: whole planes go up,
+ * the test runs, the booleans and the count come back, in chunks of 2^24 pairs so that a batch of any size
+ * needs at most 1 GB of device memory (kept by the ctx from the first call on).  It runs at the rate of the
+ * host-to-device link, which carries 64 and 40 bytes per pair and is 95 % of the call (pipelined forms were
+ * measured and are slower: csrc/c2d_host.hip).  h_planes / h_pose_planes: host planes as for the device entry
+ * points, pageable or page-locked; h_out: host u8[n]; h_count: optional host word that receives the number of
+ * colliding pairs.  Uses the ctx's count workspace like the device entry points.  Returns when h_out is complete. */
+int c2d_sat_rect_pairs_verts_host(c2d_ctx* ctx, const float* const h_planes[16], size_t n, uint8_t* h_out,
+                                  unsigned long long* h_count);
+int c2d_sat_rect_pairs_pose_host(c2d_ctx* ctx, const float* const h_pose_planes[10], size_t n, uint8_t* h_out,
+                                 unsigned long long* h_count);
+
 /* c2d_sat_poly_pairs: SAT for arbitrary convex polygons with up to
  * C2D_POLY_KMAX vertices.  Same projection / strict-< interval test as
  * utils.cu:172-180, but the axis of edge e is its true normal (-e.y, e.x):
