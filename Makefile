@@ -38,7 +38,7 @@ clean:
 	rm -f $(OBJS) $(LIBDIR)/libc2d.so $(BINDIR)/generate_dataset $(BINDIR)/compute_collision_probability $(BINDIR)/ztest
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle drivers tools clean lib-fmad lib-nopretest lib-rehearsal lib-mcstats
+.PHONY: all lib oracle drivers tools clean lib-fmad lib-nopretest lib-rehearsal lib-mcstats lib-mcclock
 
 # developer tools (not shipped in libc2d.so)
 TOOLS := $(CSRC)/tools/sat_tune $(CSRC)/tools/pose_probe $(CSRC)/tools/clock_probe $(CSRC)/tools/instr_probe
@@ -79,3 +79,11 @@ $(CSRC)/c2d_mc_stats.o: $(CSRC)/c2d_mc.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -DC2D_MC_STATS -c $< -o $@
 $(LIBDIR)/libc2d_mcstats.so: $(OBJS) $(CSRC)/c2d_mc_stats.o
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(filter-out $(CSRC)/c2d_mc.o,$(OBJS)) $(CSRC)/c2d_mc_stats.o -ldl
+
+# clock build (developer tool, not part of `all`): Monte-Carlo kernels that stamp s_memtime / s_memrealtime around their sample work
+# (C2D_MC_CLOCK in c2d_mc_core.hpp); tests/tools/mc_clock.py reads the stamps and records the clock the kernels hold
+lib-mcclock: $(LIBDIR)/libc2d_mcclock.so
+$(CSRC)/c2d_mc_clock.o: $(CSRC)/c2d_mc.hip $(HDRS)
+	$(HIPCC) $(HIPFLAGS) -DC2D_MC_CLOCK -c $< -o $@
+$(LIBDIR)/libc2d_mcclock.so: $(OBJS) $(CSRC)/c2d_mc_clock.o
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(filter-out $(CSRC)/c2d_mc.o,$(OBJS)) $(CSRC)/c2d_mc_clock.o -ldl

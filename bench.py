@@ -64,6 +64,23 @@ def measured_counts():
         return {}
 
 
+NOMINAL_GHZ = 2.4
+
+
+def held_clock(roofline: dict, c: dict) -> None:
+    """The VALU peak of MI355X_MICROARCH.md is priced at the nominal 2.4 GHz; under a dense VALU load the chip holds less.  Where the
+    clock build of the kernel has recorded the clock its waves held (tests/tools/mc_clock.py -> measured_counts.json), the roofline
+    also carries the peak and the fraction at THAT clock."""
+    ghz = c.get("held_clock_ghz")
+    if not ghz:
+        return
+    peak = roofline["peak"] * ghz / NOMINAL_GHZ
+    roofline["held_clock_ghz"] = ghz
+    roofline["peak_at_held_clock"] = round(peak, 2)
+    roofline["frac_at_held_clock"] = round(roofline["achieved"] / peak, 4)
+    roofline["held_clock_source"] = "recorded, not measured in this run: %s" % c.get("held_clock_source")
+
+
 def self_launch(n_gpus: int) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks as fresh processes.  This parent has not
     imported torch and never touches a GPU; it relays rank 0's JSON line and the children's exit status."""
@@ -417,6 +434,51 @@ def main() -> None:
                                                  "pair test (round 3) took the kernel from 294 to the recorded instruction count per pair"}
             pose_leg["roofline"]["traffic"] = c.get("hbm_bytes_per_launch")
             pose_leg["roofline"]["traffic_source"] = "recorded, not measured in this run: %s" % c.get("source")
+    # ---- the same batch starting in HOST memory (include/c2d.h c2d_sat_rect_pairs_*_host): never `value` — the link is the bound ---
+    host_leg = None
+    if not args.no_pose and rank == 0 and world == 1:
+        import ctypes as C
+
+        pin = eng.host_empty((16, n), np.float32)
+        pin[:] = planes.cpu().numpy()
+        pin_pose = eng.host_empty((10, n), np.float32)
+        pin_pose[:] = pose.cpu().numpy()
+        h_res = eng.host_empty(n, np.uint8)
+        d_tmp = eng.empty((16, n), np.float32)
+
+        def link_copy():
+            eng._check(eng.lib.c2d_memcpy_h2d(eng.h, C.c_void_p(d_tmp.ptr), C.c_void_p(pin.ctypes.data), pin.nbytes, None), "c2d_memcpy_h2d")
+            eng.synchronize()
+
+        def best_of(fn, k=4):
+            b = 1e9
+            for _ in range(k):
+                t_ = time.perf_counter()
+                fn()
+                b = min(b, time.perf_counter() - t_)
+            return b
+
+        link_gbs = pin.nbytes / best_of(link_copy) / 1e9
+        d_tmp.free()
+        gpu_bools = out.cpu().numpy()
+        host_leg = {"note": "the batch starts and ends in host memory (page-locked): upload, test, download in one synchronous call; bound by the "
+                            "host-to-device link, reported as a fraction of one large page-locked copy measured in this run; never the headline value",
+                    "link_h2d_GBs": round(link_gbs, 1)}
+        for fmt, arr, bpp in (("verts", pin, 64), ("pose", pin_pose, 40)):
+            cnt_box = {}
+
+            def call():
+                cnt_box["c"] = eng.sat_rect_pairs_host([arr[k] for k in range(arr.shape[0])], h_res, fmt)
+
+            t_host = best_of(call)
+            same = int((h_res == gpu_bools).sum())
+            if same != n:
+                raise SystemExit(f"PARITY FAILURE: host-resident {fmt} entry point differs from the device entry point on {n - same} of {n} pairs")
+            host_leg[fmt] = {"pairs_per_s": n / t_host, "ms": round(t_host * 1e3, 3), "bytes_up_per_pair": bpp,
+                             "GBs_up": round(bpp * n / t_host / 1e9, 1), "frac_of_link": round(bpp * n / t_host / 1e9 / link_gbs, 3),
+                             "parity": f"booleans equal to the device entry point's on {same} of {n} pairs", "colliding": cnt_box["c"]}
+        for a_ in (pin, pin_pose, h_res):
+            eng.host_free(a_)
     del pose
 
     # ---- Monte-Carlo leg: config 3 --------------------------------------------------------
@@ -464,6 +526,7 @@ def main() -> None:
                               "unit": "T VALU lane-instr/s per GPU (peak = 157.3 TFLOP/s / 2 flop per FMA)",
                               "frac": round(lane_ops / VALU_PEAK_TLANE, 4), "valu_instr_per_sample": c["valu_instr_per_sample"],
                               "instr_source": c.get("source")}
+            held_clock(mc["roofline"], c)
 
     # ---- Monte-Carlo over convex polygons (README.md:3 "arbitrary convex 2D shapes"; include/c2d.h c2d_mc_poly_pair) -------------
     mc_poly = None
@@ -559,6 +622,7 @@ def main() -> None:
                                       "valu_instr_per_sample": c["valu_instr_per_sample"], "instr_source": c.get("source"),
                                       "note": "instructions per DRAWN sample: most samples of this workload are certain misses decided from "
                                               "their radius word, four words per Philox block (DESIGN.md §5); ~0 HBM bytes per sample"}
+            held_clock(scenes_leg["roofline"], c)
             if c.get("evaluated_fraction"):
                 scenes_leg["evaluated_samples_per_s"] = float(hsum[1].item()) / sel * c["evaluated_fraction"]
                 scenes_leg["evaluated_fraction"] = c["evaluated_fraction"]
@@ -866,7 +930,7 @@ def main() -> None:
                        "parallelism": f"pairs sharded over {world} GPU(s), one process per GPU, no data-path collective, one sum of the hit count per leg",
                        "reduce": reduce_impl,
                        "ranks_in_reduce": (cdist.world_size if cdist is not None else (dist.get_world_size() if use_dist else 1))},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "mask_output": mask_leg, "pose_format": pose_leg, "mc": mc, "mc_poly": mc_poly, "scenes": scenes_leg, "poly": poly_leg,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "mask_output": mask_leg, "pose_format": pose_leg, "host_resident": host_leg, "mc": mc, "mc_poly": mc_poly, "scenes": scenes_leg, "poly": poly_leg,
             "device": eng.info()["name"],
         }
         sys.stdout.flush()

@@ -49,6 +49,13 @@ __device__ unsigned long long c2d_mc_stats_words[12];
 
 #include "c2d_mc_core.hpp"  // the shape-independent part: draw layout, NEAR / FAR sample loops, queues
 
+#ifdef C2D_MC_CLOCK
+namespace c2d {
+C2D_MC_CLOCK_WORDS(c2d_mc_clock_pair);     // mc_pair_kernel
+C2D_MC_CLOCK_WORDS(c2d_mc_clock_scenes);   // mc_scenes_advance_kernel
+}  // namespace c2d
+#endif
+
 namespace c2d {
 
 // Wave-uniform description of one scene (reference ccp.cu:119-133).
@@ -601,12 +608,14 @@ __global__ __launch_bounds__(kMcBlock, C2D_MC_PAIR_WAVES) void mc_pair_kernel(Pa
     const Scene sc = park_exact(make_scene(A.robot_w, A.robot_h, A.px, A.py, A.pose, A.sd), s_queue[wave]);  // (EVAL group in registers: see park_scene)
     const uint64_t n_chunks = (A.n_samples + A.chunk - 1) / A.chunk;
     unsigned long long total = 0;
+    C2D_MC_CLOCK_START();
     for (uint64_t ch = (uint64_t)blockIdx.x * kWavesPerBlock + wave; ch < n_chunks; ch += (uint64_t)gridDim.x * kWavesPerBlock) {
         const uint64_t off = ch * A.chunk;
         const uint64_t left = A.n_samples - off;
         const uint32_t count = left < A.chunk ? (uint32_t)left : A.chunk;
         total += wave_count_hits<RectPolicy<false>>(sc, A.seed, A.scene_id, A.sample_begin + off, count, s_queue[wave]);
     }
+    C2D_MC_CLOCK_STOP(c2d_mc_clock_pair);
     if ((threadIdx.x & 63) == 0 && total) atomicAdd(d_hits, total);
 }
 
@@ -636,6 +645,9 @@ struct ScenesArgs {
 struct RectBuilder {
     using Args = ScenesArgs;
     using Policy = RectPolicy<kParkAdaptive>;
+#ifdef C2D_MC_CLOCK
+    static C2D_DEV unsigned long long* clock_words() { return c2d_mc_clock_scenes; }
+#endif
     static C2D_DEV Scene scene(const Args& A, const PositionWithVarAndPoseIdx& row, WaveQueue& q)
     {
         // float -> int index conversion as in ccp.cu:121-122; clamped so that a malformed row cannot read outside the tables
@@ -957,6 +969,25 @@ int c2d_sample_scenes(c2d_ctx* ctx, const Pose* d_poses, uint32_t num_poses, con
     C2D_LAUNCH_CHECK(ctx);
     return C2D_OK;
 }
+
+#ifdef C2D_MC_CLOCK
+// clock build only: the stamps of mc_pair_kernel (which = 0) or of mc_scenes_advance_kernel (1): shader cycles, 100 MHz ticks, waves
+int c2d_debug_mc_clock(c2d_ctx* ctx, int which, unsigned long long out[4], int reset)
+{
+    if (!ctx || !out || which < 0 || which > 1) return C2D_ERR_INVALID_ARG;
+    DeviceGuard g(ctx->device);
+    C2D_HIP(ctx, hipDeviceSynchronize());
+    const unsigned long long zero[4] = {};
+    if (which == 0) {
+        C2D_HIP(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(c2d_mc_clock_pair), 4 * sizeof(unsigned long long)));
+        if (reset) C2D_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c2d_mc_clock_pair), zero, sizeof zero));
+    } else {
+        C2D_HIP(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(c2d_mc_clock_scenes), 4 * sizeof(unsigned long long)));
+        if (reset) C2D_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c2d_mc_clock_scenes), zero, sizeof zero));
+    }
+    return C2D_OK;
+}
+#endif
 
 #ifdef C2D_MC_STATS
 // census build only: copies the twelve counters to the host (after synchronising the device) and optionally clears them

@@ -22,6 +22,32 @@
 #define C2D_MC_STAT(i, v) do { } while (0)
 #endif
 
+// ---- clock build (-DC2D_MC_CLOCK, `make lib-mcclock`; never the product): which clock do the Monte-Carlo kernels HOLD?  Every
+// wave reads the shader-cycle counter (s_memtime) and the constant 100 MHz counter (s_memrealtime) when its sample work starts
+// and when it ends, and adds both differences to two device words; their ratio x 100 MHz is the time-weighted clock the waves
+// ran at.  The VALU rooflines of bench.py are priced at that clock beside the nominal 2.4 GHz (tests/tools/mc_clock.py).
+#ifdef C2D_MC_CLOCK
+#define C2D_MC_CLOCK_WORDS(name) __device__ unsigned long long name[4]   /* shader cycles, 100 MHz ticks, waves, unused */
+struct McClockStamp {
+    unsigned long long c0, r0;
+    __device__ __forceinline__ McClockStamp() : c0(__builtin_amdgcn_s_memtime()), r0(__builtin_amdgcn_s_memrealtime()) {}
+    __device__ __forceinline__ void stop(unsigned long long* words) const
+    {
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&words[0], c1 - c0);
+            atomicAdd(&words[1], r1 - r0);
+            atomicAdd(&words[2], 1ull);
+        }
+    }
+};
+#define C2D_MC_CLOCK_START() const McClockStamp clock_stamp__
+#define C2D_MC_CLOCK_STOP(words) clock_stamp__.stop(words)
+#else
+#define C2D_MC_CLOCK_START() do { } while (0)
+#define C2D_MC_CLOCK_STOP(words) do { } while (0)
+#endif
+
 namespace c2d {
 
 // One wave per block: a multi-wave block keeps its LDS and its place until the slowest of its waves is done, and the
@@ -428,6 +454,7 @@ C2D_DEV void mc_scenes_advance_body(const typename B::Args& A)
     wps = (n_batch + chunk - 1) / chunk;
 
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    C2D_MC_CLOCK_START();
     if constexpr (BURST) {  // first launch of a call: n_start == 0, identity list, one work item per scene
         for (uint64_t item = (uint64_t)blockIdx.x * kWavesPerBlock + wave; item < n_active; item += (uint64_t)gridDim.x * kWavesPerBlock) {
             const uint32_t g = (uint32_t)item;
@@ -455,6 +482,7 @@ C2D_DEV void mc_scenes_advance_body(const typename B::Args& A)
                 }
             }
         }
+        C2D_MC_CLOCK_STOP(B::clock_words());
         return;
     }
     const uint64_t n_items = (uint64_t)n_active * wps;
@@ -470,6 +498,7 @@ C2D_DEV void mc_scenes_advance_body(const typename B::Args& A)
         const uint32_t h = wave_count_hits<P>(sc, A.seed, A.scene_id_base + g, (uint64_t)n_start + off, count, s_queue[wave]);
         if ((threadIdx.x & 63) == 0 && h) atomicAdd(&A.hits[g], h);
     }
+    C2D_MC_CLOCK_STOP(B::clock_words());
 }
 
 // After a batch: stop test of ccp.cu:140-148 per active scene, compaction of the

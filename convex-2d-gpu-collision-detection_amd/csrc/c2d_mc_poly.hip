@@ -376,9 +376,16 @@ struct PolyScenesArgs {
     uint32_t* async_err;
 };
 
+#ifdef C2D_MC_CLOCK
+C2D_MC_CLOCK_WORDS(c2d_mc_clock_poly);   // (the polygon kernels are stamped too, for completeness; no reader yet)
+#endif
+
 struct PolyBuilder {
     using Args = PolyScenesArgs;
     using Policy = PolyPolicy;
+#ifdef C2D_MC_CLOCK
+    static C2D_DEV unsigned long long* clock_words() { return c2d_mc_clock_poly; }
+#endif
     static C2D_DEV PolyScene scene(const Args& A, const PositionWithVarAndPoseIdx& row, PolyQueue& q)
     {
         // float -> int index conversion as in ccp.cu:121-122; clamped so that a malformed row cannot read outside the tables

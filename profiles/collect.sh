@@ -27,6 +27,9 @@ python3 convex-2d-gpu-collision-detection_amd/csrc/tools/scenes_trace.py digest 
 cp $O/bench.json profiles/${TAG}_bench.json
 cp $O/bench_under_rocprof.json profiles/${TAG}_bench_under_rocprof.json
 python3 profiles/counts.py write $TAG   # measured_counts.json is generated from this tag's digests (tests/test_profiles.py verifies it)
+# fields other builds record into it: the census build's evaluated-sample fraction, the clock build's held clock (make lib-mcstats lib-mcclock)
+if [ -f convex-2d-gpu-collision-detection_amd/lib/libc2d_mcstats.so ]; then echo "== census"; timeout -k 10 400 python3 tests/tools/mc_stats.py --record > profiles/${TAG}_mc_stats.txt 2>&1 || echo "census failed"; fi
+if [ -f convex-2d-gpu-collision-detection_amd/lib/libc2d_mcclock.so ]; then echo "== held clock"; timeout -k 10 400 python3 tests/tools/mc_clock.py --record $TAG > profiles/${TAG}_mc_clock.txt 2>&1 || echo "clock failed"; fi
 # the bench line quotes measured_counts.json (instruction counts, PMC traffic): run it again now that the file is this tag's own,
 # so that the committed line never carries the previous collection's counts for a kernel that has changed since
 echo "== un-profiled bench again, with this tag's counts"; (cd /tmp && timeout -k 10 500 python3 $R/bench.py > $O/bench.json 2> $O/bench.err)
