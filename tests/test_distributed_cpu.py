@@ -1,4 +1,4 @@
-"""world_size-2 gloo tests of the multi-GPU path's host logic: range
+"""world_size-2, -3 and -8 gloo tests of the multi-GPU path's host logic: range
 sharding + one all-reduce of the counters.  The per-rank compute here is the CPU oracle
 (test stand-in for the HIP kernels, which need a GPU); the property under test is that
 shards + reduce reproduce the single-process result exactly."""
@@ -83,10 +83,12 @@ def test_shard_range_partitions_exactly(pkg):
         sh.shard_range(10, 2, 2)
 
 
-def test_two_rank_gloo_sharding_reproduces_single_process(oracle, wl):
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_gloo_sharding_reproduces_single_process(oracle, wl, world):
+    """2, 3 and 8 ranks (the arithmetic of shard_range, scene_id_base and the counter reduce at the world size of the first real
+    8-GPU lease, with a world that does not divide the work and one with fewer scenes per rank than ranks)"""
     import torch.multiprocessing as mp
 
-    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -108,4 +110,4 @@ def test_two_rank_gloo_sharding_reproduces_single_process(oracle, wl):
     scenes = oracle.sample_scenes(tp, ts, 4.07, 1.74, 4.0, 5, 0, 41)
     h, u, _, tot = oracle.mc_scenes(tp, ts, scenes, 4.07, 1.74, [0, .01, .1, 1], [1e-4, 1e-3, 1e-2], 2000, 8, 0)
     assert scene_hits == int(h.sum()) and scene_samples == tot
-    assert tmax == 2.0
+    assert tmax == float(world)
