@@ -93,9 +93,18 @@ def self_launch(n_gpus: int) -> int:
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    # The port was free a moment ago; if something took it before the launcher bound it (its rendezvous then fails with EADDRINUSE
+    # before any rank has started), pick another one.  Nothing else is ever retried.
+    for attempt in range(3):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+        sys.stderr.write(proc.stderr)
+        if proc.returncode == 0 or "EADDRINUSE" not in proc.stderr or '"metric"' in proc.stdout:
+            break
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
     line = None
     for ln in proc.stdout.splitlines():
         ln = ln.strip()
@@ -550,11 +559,11 @@ def main() -> None:
         for _ in range(args.mc_reps):
             mc_poly_step()
         pe1.record(stream)
-        mc_poly_hits_one_step = int(phits.item()) // args.mc_reps if world == 1 else None
         all_reduce_sum(phits)
         torch.cuda.synchronize()
         barrier()
         pmel = shd.max_over_ranks(time.perf_counter() - pm0, dev)
+        mc_poly_hits_one_step = int(phits.item()) // args.mc_reps if world == 1 else None  # (every rep repeats the same samples)
         mc_poly_ms = pe0.elapsed_time(pe1) / args.mc_reps
         mc_poly = {"metric": "mc_poly_samples_per_s", "value": PS * world * args.mc_reps / pmel, "samples_per_gpu": PS, "reps": args.mc_reps,
                    "kernel_ms": round(mc_poly_ms, 4), "probability": float(phits.item()) / (PS * world * args.mc_reps),

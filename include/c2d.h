@@ -255,7 +255,9 @@ int c2d_sat_poly_pairs_rows(c2d_ctx* ctx, const float* d_vx, const float* d_vy, 
  *                          count outside 1..rows is refused (C2D_ERR_INVALID_ARG, no handle).
  *   c2d_poly_bins_results  for a handle made by c2d_poly_bins_from_padded: the results in the
  *                          ORDER OF THE PADDED INPUT, u8[n] (asynchronous on `stream`);
- *   c2d_poly_bins_get      descriptor i of the handle (device pointers), for inspection. */
+ *   c2d_poly_bins_get      descriptor i of the handle (device pointers), for inspection: bin i of
+ *                          c2d_poly_bins_create is the caller's bin i (a bin with n = 0 stays in the list and
+ *                          takes no work). */
 typedef struct c2d_poly_bin {
     uint32_t rows_a, rows_b;
     size_t n;

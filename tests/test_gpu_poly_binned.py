@@ -131,7 +131,11 @@ def test_user_bins_of_every_shape(eng, oracle, wl, counted, extent, stride_pad):
              (4, 4, 0), (5, 11, 1), (10, 10, 1000), (13, 14, 65), (6, 6, 4096), (7, 2, 191)]
     bins, host, bufs = _upload_user_bins(eng, rng, specs, extent, wl, counted, stride_pad, seed=1000 * counted)
     handle = eng.poly_bins_create(bins)
-    assert len(handle) == sum(1 for s in specs if s[2]) and handle.pairs == sum(s[2] for s in specs)
+    # the handle's bin i is the caller's bin i, empty ones included (they take no tiles): c2d_poly_bins_get never renumbers
+    assert len(handle) == len(specs) and handle.pairs == sum(s[2] for s in specs)
+    for i, (ra, rb, n) in enumerate(specs):
+        g = handle.get(i)
+        assert (g["rows_a"], g["rows_b"], g["n"]) == (ra, rb, n) and g["out"] == bins[i]["out"].ptr
     d_cnt = eng.zeros(1, np.uint64)
     eng.sat_poly_pairs_binned(handle, d_cnt)
     eng.sat_poly_pairs_binned(handle, None)            # the count is optional; results are rewritten identically
