@@ -51,7 +51,7 @@ extern "C" {
 #endif
 
 #define C2D_VERSION_MAJOR 0
-#define C2D_VERSION_MINOR 3
+#define C2D_VERSION_MINOR 4
 
 /* ---- status codes ------------------------------------------------------ */
 #define C2D_OK 0
