@@ -587,6 +587,7 @@ struct RectPolicy {
     {
         return wave_count_hits_plain<PARKED>(sc, seed, scene_id, begin, count, wq);
     }
+    static C2D_DEV uint32_t finish(const Scene&, Queue&) { return 0u; }  // (a rectangle's evaluation is one stage: nothing is held back)
 };
 
 // ---- one scene, sample-parallel (BASELINE config 3) -------------------------------

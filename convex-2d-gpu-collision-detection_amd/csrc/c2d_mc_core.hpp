@@ -10,6 +10,8 @@
 //              centres are (dx, dy): the rest of the sample (second / third Box-Muller pair, rotation, shape) and the test
 //   P::plain(sc, seed, scene_id, begin, count, wq)   hits of a scene that is not tame: every sample evaluated in full, for
 //              every bit pattern
+//   P::finish(sc, wq)   hits among whatever P::evaluate has held back (a policy may evaluate in stages and keep the survivors of
+//              the first stage in a queue of its own until 64 have gathered); called once at the end of a sample range
 //
 // The draw layout (groups of four samples, c2d_math.hpp), the two ways to run a scene (NEAR / FAR), the queues and the
 // compaction are the same for every shape; DESIGN.md §5 has the measurements behind them.
@@ -359,13 +361,13 @@ C2D_DEV uint32_t wave_count_hits(const typename P::Scene& sc, uint64_t seed, uin
 #ifndef C2D_MC_NO_PRETEST  // validation builds evaluate every sample in full
     if (sc.use_x0 && sc.x0 < kFarX0) {
         C2D_MC_STAT(1, count);
-        const uint32_t h = wave_count_hits_far<P>(sc, seed, scene_id, begin, count, q);
+        const uint32_t h = wave_count_hits_far<P>(sc, seed, scene_id, begin, count, q) + P::finish(sc, q);
         C2D_MC_STAT(7, h);
         return h;
     }
 #endif
     C2D_MC_STAT(2, count);
-    const uint32_t h = wave_count_hits_near<P>(sc, seed, scene_id, begin, count, q);
+    const uint32_t h = wave_count_hits_near<P>(sc, seed, scene_id, begin, count, q) + P::finish(sc, q);
     C2D_MC_STAT(7, h);
     return h;
 }

@@ -23,6 +23,7 @@
 namespace c2d {
 
 constexpr int KM = C2D_POLY_KMAX;
+constexpr int kSurvSlots = 128;  // < 64 left over + at most 64 pushed by one evaluation pass
 
 // wave-uniform description of a polygon scene; the bulk lives in PolyQueue
 struct PolyScene {
@@ -40,6 +41,10 @@ struct PolyQueue {
     float4 pre[KM];     // centre pretest on that normal: certain miss if T < plo or T > phi; .z = the robot's FIRST projection
     float2 rvert[KM];   // robot vertices, placed
     float2 overt[KM];   // obstacle vertices in the obstacle frame
+    // survivors of the first stage of an evaluation (no robot normal separates them), waiting for the second on 64 busy lanes
+    float4 surv_a[kSurvSlots];   // dx, dy, cos, sin of the sampled pose
+    float2 surv_b[kSurvSlots];   // the two scale factors
+    uint32_t n_surv;             // wave-uniform; 0 whenever a sample range starts or ends
     SampleQueues sq;
 };
 
@@ -94,6 +99,7 @@ C2D_DEV PolyScene build_poly_scene(float rvx, float rvy, int ka, float px, float
         q.rvert[l] = make_float2(wx, wy);
         q.overt[l] = make_float2(oxl, oyl);
     }
+    if (lane == 0) q.n_surv = 0;
     wave_lds_sync();
     // edge l: from slot l to slot l + 1 (mod 16); with the padding above that is the polygon's closing edge for l = ka - 1 and a
     // zero-length edge beyond it
@@ -147,16 +153,19 @@ C2D_DEV PolyScene build_poly_scene(float rvx, float rvy, int ka, float px, float
     return sc;
 }
 
-// ---- full evaluation of one sample per lane: the sampled obstacle (the oracle's sample_polygon) and the interval test on all
-// ka + kb true normals.  CB = the obstacle's vertex slots held in registers (kb rounded up to an even number; a padding slot
-// is neutral).  NANS: the scene is not tame, so a projection may be a NaN and the comparison-based extremes of
-// thrust::minmax_element (utils.cu:176-177) must be followed: one unordered compare of the two first projections per axis
-// (first_projections_ordered, c2d_math.hpp).  Returns the lanes of `lanes` whose sample collides.
-template <int CB, bool NANS>
-C2D_DEV unsigned long long poly_sample_collides(const PolyScene& sc, const PolyQueue& q, float dx, float dy, float c, float s, float fx, float fy,
-                                                unsigned long long lanes)
+// ---- evaluation of one sample per lane, in two stages.  Both build the sampled obstacle in registers (the oracle's
+// sample_polygon: scale, rotate, move — the same floats both times) and run the interval test of utils.cu:172-180 on true normals:
+//   stage A  the robot's ka normals (its own interval is wave-uniform): 4 kb instructions per normal;
+//   stage B  the obstacle's kb normals, four at a time (own interval from the registers, the robot's vertices as LDS broadcasts):
+//            4 (ka + kb) per normal — two thirds to three quarters of an evaluation.
+// The result is an OR over normals, so a sample that stage A separates is decided: only its survivors need stage B, and they are
+// queued until 64 have gathered (PolyPolicy::evaluate) so that stage B always runs on busy lanes.  CB = the obstacle's vertex slots
+// held in registers (kb rounded up to an even number; a padding slot is neutral).  NANS: the scene is not tame, so a projection may
+// be a NaN and the comparison-based extremes of thrust::minmax_element (utils.cu:176-177) must be followed: one unordered compare
+// of the two first projections per axis (first_projections_ordered, c2d_math.hpp).
+template <int CB>
+C2D_DEV void poly_sampled_vertices(const PolyQueue& q, float dx, float dy, float c, float s, float fx, float fy, float (&ox)[CB], float (&oy)[CB])
 {
-    float ox[CB], oy[CB];
 #pragma unroll
     for (int k = 0; k < CB; k++) {
         const float2 b = q.overt[k];
@@ -164,8 +173,13 @@ C2D_DEV unsigned long long poly_sample_collides(const PolyScene& sc, const PolyQ
         ox[k] = dot2(c, x, -s, y) + dx;                // utils.cu:139
         oy[k] = dot2(s, x, c, y) + dy;                 // utils.cu:140
     }
+}
+
+// stage A: the lanes of `lanes` that no robot normal separates
+template <int CB, bool NANS>
+C2D_DEV unsigned long long poly_stage_robot(const PolyScene& sc, const PolyQueue& q, const float (&ox)[CB], const float (&oy)[CB], unsigned long long lanes)
+{
     unsigned long long sep = 0ull;
-    // ---- the robot's edge normals: its own interval is wave-uniform
     const int ka = sc.ka;
 #pragma nounroll
     for (int i = 0; i < ka; i++) {
@@ -182,9 +196,16 @@ C2D_DEV unsigned long long poly_sample_collides(const PolyScene& sc, const PolyQ
         if constexpr (NANS) m &= __builtin_amdgcn_ballot_w64(first_projections_ordered(q.pre[i].z, p0));
         sep |= m;
     }
-    if ((lanes & ~sep) == 0ull) return 0ull;  // every lane of the pass is separated: no other axis can change an answer
-    // ---- the obstacle's edge normals, four at a time (the last group of a class that is not a multiple of four: two): own
-    // interval from the registers, the robot's from LDS broadcasts
+    return lanes & ~sep;
+}
+
+// stage B: the lanes of `lanes` that no obstacle normal separates
+template <int CB, bool NANS>
+C2D_DEV unsigned long long poly_stage_obstacle(const PolyScene& sc, const PolyQueue& q, const float (&ox)[CB], const float (&oy)[CB], unsigned long long lanes)
+{
+    unsigned long long sep = 0ull;
+    const int ka = sc.ka;
+    // four normals at a time (the last group of a class that is not a multiple of four: two)
     auto group = [&](auto g_const, auto j0_const) {
         constexpr int G = decltype(g_const)::value, j0 = decltype(j0_const)::value;
         float nx[G], ny[G], mn1[G], mx1[G], mn2[G], mx2[G], q0[G], r0[G];
@@ -239,20 +260,36 @@ C2D_DEV unsigned long long poly_sample_collides(const PolyScene& sc, const PolyQ
     return lanes & ~sep;
 }
 
-template <bool NANS>
-C2D_DEV unsigned long long poly_sample_collides_any(const PolyScene& sc, const PolyQueue& q, float dx, float dy, float c, float s, float fx, float fy,
-                                                    unsigned long long lanes)
+// STAGE = 0: both stages in place (the plain path); 1: stage A only; 2: stage B only.  Returns the surviving lanes.
+template <int CB, bool NANS, int STAGE>
+C2D_DEV unsigned long long poly_sample_stage(const PolyScene& sc, const PolyQueue& q, float dx, float dy, float c, float s, float fx, float fy,
+                                             unsigned long long lanes)
+{
+    float ox[CB], oy[CB];
+    poly_sampled_vertices<CB>(q, dx, dy, c, s, fx, fy, ox, oy);
+    unsigned long long alive = lanes;
+    if constexpr (STAGE != 2) {
+        alive = poly_stage_robot<CB, NANS>(sc, q, ox, oy, alive);
+        if (alive == 0ull) return 0ull;  // every lane of the pass is separated: no other normal can change an answer
+    }
+    if constexpr (STAGE != 1) alive = poly_stage_obstacle<CB, NANS>(sc, q, ox, oy, alive);
+    return alive;
+}
+
+template <bool NANS, int STAGE>
+C2D_DEV unsigned long long poly_sample_stage_any(const PolyScene& sc, const PolyQueue& q, float dx, float dy, float c, float s, float fx, float fy,
+                                                 unsigned long long lanes)
 {
     const int cls = (sc.kb + 1) >> 1;  // wave-uniform: vertex slots in registers = kb rounded up to an even number
     switch (cls) {
-    case 1: return poly_sample_collides<2, NANS>(sc, q, dx, dy, c, s, fx, fy, lanes);
-    case 2: return poly_sample_collides<4, NANS>(sc, q, dx, dy, c, s, fx, fy, lanes);
-    case 3: return poly_sample_collides<6, NANS>(sc, q, dx, dy, c, s, fx, fy, lanes);
-    case 4: return poly_sample_collides<8, NANS>(sc, q, dx, dy, c, s, fx, fy, lanes);
-    case 5: return poly_sample_collides<10, NANS>(sc, q, dx, dy, c, s, fx, fy, lanes);
-    case 6: return poly_sample_collides<12, NANS>(sc, q, dx, dy, c, s, fx, fy, lanes);
-    case 7: return poly_sample_collides<14, NANS>(sc, q, dx, dy, c, s, fx, fy, lanes);
-    default: return poly_sample_collides<16, NANS>(sc, q, dx, dy, c, s, fx, fy, lanes);
+    case 1: return poly_sample_stage<2, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes);
+    case 2: return poly_sample_stage<4, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes);
+    case 3: return poly_sample_stage<6, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes);
+    case 4: return poly_sample_stage<8, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes);
+    case 5: return poly_sample_stage<10, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes);
+    case 6: return poly_sample_stage<12, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes);
+    case 7: return poly_sample_stage<14, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes);
+    default: return poly_sample_stage<16, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes);
     }
 }
 
@@ -294,12 +331,51 @@ struct PolyPolicy {
         miss_m = __builtin_amdgcn_ballot_w64(miss);
         return miss;
     }
+    // stage B for the last `take` (<= 64) queued survivors
+    static C2D_DEV uint32_t evaluate_survivors(const Scene& sc, Queue& q, uint32_t& n, uint32_t take)
+    {
+        const uint32_t lane = threadIdx.x & 63;
+        wave_lds_sync();
+        const unsigned long long live_m = take >= 64 ? ~0ull : (1ull << take) - 1;
+        const uint32_t src = n - take + (lane < take ? lane : 0);
+        const float4 a = q.surv_a[src];
+        const float2 b = q.surv_b[src];
+        wave_lds_sync();
+        n -= take;
+        return (uint32_t)__popcll(poly_sample_stage_any<false, 2>(sc, q, a.x, a.y, a.z, a.w, b.x, b.y, live_m));
+    }
     static C2D_DEV uint32_t evaluate(const Scene& sc, Queue& q, uint32_t w2r, uint32_t w2a, float dx, float dy, uint64_t seed, uint64_t scene_id, uint64_t sample,
                                      unsigned long long live_m)
     {
         float c, s, fx, fy;
         poly_sample_shape(sc, w2r, w2a, seed, scene_id, sample, c, s, fx, fy);
-        return (uint32_t)__popcll(poly_sample_collides_any<false>(sc, q, dx, dy, c, s, fx, fy, live_m));
+        const unsigned long long alive = poly_sample_stage_any<false, 1>(sc, q, dx, dy, c, s, fx, fy, live_m);
+        if (alive == 0ull) return 0u;
+        uint32_t n = q.n_surv;  // (wave-uniform: every lane reads the same word)
+        if ((alive >> (threadIdx.x & 63)) & 1ull) {
+            const uint32_t slot = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(alive >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)alive, 0u));
+            q.surv_a[slot] = make_float4(dx, dy, c, s);
+            q.surv_b[slot] = make_float2(fx, fy);
+        }
+        n += (uint32_t)__popcll(alive);
+        uint32_t hits = 0;
+        if (n >= 64) hits = evaluate_survivors(sc, q, n, 64);
+        wave_lds_sync();
+        if ((threadIdx.x & 63) == 0) q.n_surv = n;
+        wave_lds_sync();
+        return hits;
+    }
+    // the survivors still queued when a sample range ends
+    static C2D_DEV uint32_t finish(const Scene& sc, Queue& q)
+    {
+        uint32_t n = q.n_surv;
+        if (n == 0) return 0u;
+        uint32_t hits = 0;
+        while (n) hits += evaluate_survivors(sc, q, n, n < 64 ? n : 64u);
+        wave_lds_sync();
+        if ((threadIdx.x & 63) == 0) q.n_surv = 0;
+        wave_lds_sync();
+        return hits;
     }
     // a scene that is not tame: one sample per lane, no pretest, the all-bit-patterns test
     static C2D_DEV uint32_t plain(const Scene& sc, uint64_t seed, uint64_t scene_id, uint64_t begin, uint32_t count, const Queue& q)
@@ -317,7 +393,7 @@ struct PolyPolicy {
             float dx, dy, c, s, fx, fy;
             sample_centre(sc, u4_word(b0, (int)j), u4_word(b1, (int)j), dx, dy);
             poly_sample_shape(sc, (j & 1u) ? b2.z : b2.x, (j & 1u) ? b2.w : b2.y, seed, scene_id, sm, c, s, fx, fy);
-            hits += (uint32_t)__popcll(poly_sample_collides_any<true>(sc, q, dx, dy, c, s, fx, fy, live_m));
+            hits += (uint32_t)__popcll(poly_sample_stage_any<true, 0>(sc, q, dx, dy, c, s, fx, fy, live_m));
         }
         return hits;
     }

@@ -34,7 +34,7 @@ if [ -f convex-2d-gpu-collision-detection_amd/lib/libc2d_mcclock.so ]; then echo
 # so that the committed line never carries the previous collection's counts for a kernel that has changed since
 echo "== un-profiled bench again, with this tag's counts"; (cd /tmp && timeout -k 10 500 python3 $R/bench.py > $O/bench.json 2> $O/bench.err)
 cp $O/bench.json profiles/${TAG}_bench.json
-mkdir -p $R/gpurun_out/${TAG}_profiles && cp profiles/${TAG}_* $R/gpurun_out/${TAG}_profiles/
+mkdir -p $R/gpurun_out/${TAG}_profiles && cp profiles/${TAG}_* profiles/measured_counts.json $R/gpurun_out/${TAG}_profiles/   # (only gpurun_out/ travels back from the GPU box)
 # the raw traces are large: keep only what the digests came from, compressed
 find $O -name "*.csv" -size +2M -exec gzip -f {} \;
 find $O -name "*.gz" -size +20M -delete
