@@ -260,36 +260,43 @@ C2D_DEV unsigned long long poly_stage_obstacle(const PolyScene& sc, const PolyQu
     return lanes & ~sep;
 }
 
-// STAGE = 0: both stages in place (the plain path); 1: stage A only; 2: stage B only.  Returns the surviving lanes.
+// STAGE = 0: both stages in place (the plain path); 1: stage A, and stage B in place when most of the pass survives (`final`
+// says which: true = the returned lanes are the colliding ones, false = they are stage A's survivors); 2: stage B only.
+#ifndef C2D_MC_POLY_IN_PLACE
+#define C2D_MC_POLY_IN_PLACE 48  // survivors of a pass from which stage B runs in place: the queue (two LDS round trips and the vertices
+#endif                           // built a second time) costs more than the idle lanes it would fill (32 / 40 / 48: profiles/notes_r04_mc_poly.md)
 template <int CB, bool NANS, int STAGE>
 C2D_DEV unsigned long long poly_sample_stage(const PolyScene& sc, const PolyQueue& q, float dx, float dy, float c, float s, float fx, float fy,
-                                             unsigned long long lanes)
+                                             unsigned long long lanes, bool& final)
 {
     float ox[CB], oy[CB];
     poly_sampled_vertices<CB>(q, dx, dy, c, s, fx, fy, ox, oy);
     unsigned long long alive = lanes;
+    final = true;
     if constexpr (STAGE != 2) {
         alive = poly_stage_robot<CB, NANS>(sc, q, ox, oy, alive);
         if (alive == 0ull) return 0ull;  // every lane of the pass is separated: no other normal can change an answer
     }
-    if constexpr (STAGE != 1) alive = poly_stage_obstacle<CB, NANS>(sc, q, ox, oy, alive);
-    return alive;
+    if constexpr (STAGE == 1) {
+        if (__popcll(alive) < C2D_MC_POLY_IN_PLACE) { final = false; return alive; }
+    }
+    return poly_stage_obstacle<CB, NANS>(sc, q, ox, oy, alive);
 }
 
 template <bool NANS, int STAGE>
 C2D_DEV unsigned long long poly_sample_stage_any(const PolyScene& sc, const PolyQueue& q, float dx, float dy, float c, float s, float fx, float fy,
-                                                 unsigned long long lanes)
+                                                 unsigned long long lanes, bool& final)
 {
     const int cls = (sc.kb + 1) >> 1;  // wave-uniform: vertex slots in registers = kb rounded up to an even number
     switch (cls) {
-    case 1: return poly_sample_stage<2, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes);
-    case 2: return poly_sample_stage<4, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes);
-    case 3: return poly_sample_stage<6, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes);
-    case 4: return poly_sample_stage<8, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes);
-    case 5: return poly_sample_stage<10, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes);
-    case 6: return poly_sample_stage<12, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes);
-    case 7: return poly_sample_stage<14, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes);
-    default: return poly_sample_stage<16, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes);
+    case 1: return poly_sample_stage<2, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes, final);
+    case 2: return poly_sample_stage<4, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes, final);
+    case 3: return poly_sample_stage<6, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes, final);
+    case 4: return poly_sample_stage<8, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes, final);
+    case 5: return poly_sample_stage<10, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes, final);
+    case 6: return poly_sample_stage<12, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes, final);
+    case 7: return poly_sample_stage<14, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes, final);
+    default: return poly_sample_stage<16, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes, final);
     }
 }
 
@@ -342,15 +349,17 @@ struct PolyPolicy {
         const float2 b = q.surv_b[src];
         wave_lds_sync();
         n -= take;
-        return (uint32_t)__popcll(poly_sample_stage_any<false, 2>(sc, q, a.x, a.y, a.z, a.w, b.x, b.y, live_m));
+        bool final;
+        return (uint32_t)__popcll(poly_sample_stage_any<false, 2>(sc, q, a.x, a.y, a.z, a.w, b.x, b.y, live_m, final));
     }
     static C2D_DEV uint32_t evaluate(const Scene& sc, Queue& q, uint32_t w2r, uint32_t w2a, float dx, float dy, uint64_t seed, uint64_t scene_id, uint64_t sample,
                                      unsigned long long live_m)
     {
         float c, s, fx, fy;
         poly_sample_shape(sc, w2r, w2a, seed, scene_id, sample, c, s, fx, fy);
-        const unsigned long long alive = poly_sample_stage_any<false, 1>(sc, q, dx, dy, c, s, fx, fy, live_m);
-        if (alive == 0ull) return 0u;
+        bool final;
+        const unsigned long long alive = poly_sample_stage_any<false, 1>(sc, q, dx, dy, c, s, fx, fy, live_m, final);
+        if (final) return (uint32_t)__popcll(alive);  // (nothing survived stage A, or stage B ran in place)
         uint32_t n = q.n_surv;  // (wave-uniform: every lane reads the same word)
         if ((alive >> (threadIdx.x & 63)) & 1ull) {
             const uint32_t slot = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(alive >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)alive, 0u));
@@ -393,7 +402,8 @@ struct PolyPolicy {
             float dx, dy, c, s, fx, fy;
             sample_centre(sc, u4_word(b0, (int)j), u4_word(b1, (int)j), dx, dy);
             poly_sample_shape(sc, (j & 1u) ? b2.z : b2.x, (j & 1u) ? b2.w : b2.y, seed, scene_id, sm, c, s, fx, fy);
-            hits += (uint32_t)__popcll(poly_sample_stage_any<true, 0>(sc, q, dx, dy, c, s, fx, fy, live_m));
+            bool final;
+            hits += (uint32_t)__popcll(poly_sample_stage_any<true, 0>(sc, q, dx, dy, c, s, fx, fy, live_m, final));
         }
         return hits;
     }
