@@ -343,25 +343,6 @@ __global__ __launch_bounds__(64, 5) void sat_poly_binned_kernel(const BinDesc* _
                                                                unsigned long long* __restrict__ words, uint32_t* __restrict__ async_err)
 {
     uint32_t total = 0;
-#ifdef C2D_POLY_DESC_REUSE
-    // (experiment, profiles/notes_r04_binned_kernel.md) both tiles' bin numbers are fetched up front and the descriptor is
-    // fetched again only when the second tile belongs to another bin
-    static_assert(kTilesPerWave == 2, "the descriptor-reuse form is written for two tiles per wave");
-    const uint32_t tile0 = tile_begin + blockIdx.x * 2u;
-    if (tile0 >= tile_end) return;
-    const bool two = tile0 + 1 < tile_end;
-    const uint32_t bin0 = __builtin_amdgcn_readfirstlane(tile_bin[tile0]);
-    const uint32_t bin1 = two ? __builtin_amdgcn_readfirstlane(tile_bin[tile0 + 1]) : bin0;
-    BinDesc D = bins[bin0];
-    uint32_t cur = bin0;
-#pragma nounroll
-    for (uint32_t i = 0; i < (two ? 2u : 1u); i++) {  // (ONE copy of the tile code: the kernel is 7 000 instructions as it is)
-        const uint32_t bin = i == 0 ? bin0 : bin1;
-        if (bin != cur) { D = bins[bin]; cur = bin; }
-        total += binned_tile<false>(D, tile0 + i - D.tile0, async_err);
-        __syncthreads();  // (single-wave block: a wave-level fence) the next tile reuses the LDS slots
-    }
-#else
 #pragma nounroll
     for (uint32_t i = 0; i < kTilesPerWave; i++) {
         const uint32_t tile = tile_begin + blockIdx.x * kTilesPerWave + i;
@@ -371,7 +352,6 @@ __global__ __launch_bounds__(64, 5) void sat_poly_binned_kernel(const BinDesc* _
         total += binned_tile<false>(D, tile - D.tile0, async_err);
         if (kTilesPerWave > 1) __syncthreads();  // (single-wave block: a wave-level fence) the next tile reuses the LDS slots
     }
-#endif
     if (d_count) wave_count_arrive_total2(total, d_count, words);
 }
 
