@@ -41,7 +41,7 @@ clean:
 .PHONY: all lib oracle drivers tools clean lib-fmad lib-nopretest lib-rehearsal lib-mcstats lib-mcclock
 
 # developer tools (not shipped in libc2d.so)
-TOOLS := $(CSRC)/tools/sat_tune $(CSRC)/tools/pose_probe $(CSRC)/tools/clock_probe $(CSRC)/tools/instr_probe
+TOOLS := $(CSRC)/tools/sat_tune $(CSRC)/tools/pose_probe $(CSRC)/tools/clock_probe $(CSRC)/tools/instr_probe $(CSRC)/tools/store_pattern_probe
 tools: $(TOOLS)
 $(CSRC)/tools/%: $(CSRC)/tools/%.hip $(HDRS)
 	$(HIPCC) -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -Iinclude $< -o $@

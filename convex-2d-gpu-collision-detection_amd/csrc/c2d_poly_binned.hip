@@ -503,10 +503,14 @@ struct BinMoveArgs {
 //    merge before they leave for HBM (WRITE_SIZE 2.07 -> 1.69 GB for 1.55 GB of vertices);
 //  * plane positions are element offsets from the bins' block in 32 bits (Off = uint32_t; a block of 16 GiB or more takes the
 //    64-bit instance);
-//  * the tile is 8192 pairs, one block per CU (134 KB of LDS): what limits the pass now is how well DRAM takes the WRITES —
-//    with the loads switched off the stores alone take 0.70 ms for 1.6 GB (2.3 TB/s), folded into a 32 MB window that L2 absorbs
-//    0.35 ms, and 16 bins (runs of 1 KB instead of 84 B) 0.40 ms — so the longer run per (tile, bin, row) is worth more than
-//    the second block per CU that a 4096-pair tile allows (same box: 1.27 -> 1.15 ms; whole call 1.70 -> 1.38 ms).
+//  * the tile is 8192 pairs, one block per CU (134 KB of LDS): what limits the pass now is the STORES — with the loads switched off they
+//    alone take 0.70 ms for 1.6 GB (2.3 TB/s), folded into a 32 MB window that L2 absorbs 0.35 ms.  csrc/tools/store_pattern_probe.hip
+//    shows what they are slow at: a run of whole 128-byte lines streams at 5-6 TB/s however many bins there are, the same run at an
+//    arbitrary 4-byte offset costs 2-3 times as much whatever the layout or the order — the 64-byte sectors at the two ends of a run are
+//    shared with the neighbouring tiles' runs, which other blocks write tens of microseconds earlier or later, and a tile contributes
+//    42 +- 6 pairs to a bin's row.  Hence the longer run per (tile, bin, row) is worth more than the second block per CU that a
+//    4096-pair tile allows (same box: 1.27 -> 1.15 ms; whole call 1.70 -> 1.38 ms); profiles/notes_r04_bin_move.md lists what would
+//    remove the shared sectors (an LDS carry per write front across the tiles of one block) and why it was not built.
 typedef float v4f_u __attribute__((ext_vector_type(4), aligned(4)));  // four floats at any 4-byte boundary (a row of the padded batch starts anywhere)
 #ifndef C2D_MOVE_PRODUCER_WAVES
 #define C2D_MOVE_PRODUCER_WAVES 8

@@ -2,7 +2,8 @@
 
   config 4, one GPU's shard: 4e6 data points, adaptive stopping with max_samples 120 000 —
       sharding invariance (the shard in one call == its two halves with scene_id_base set), total == sum(n_used),
-      exact per-scene hit / sample counts against the oracle on 20 random blocks of 100 scenes, and the whole shard
+      exact per-scene hit / sample counts against the oracle on 200 random blocks of 100 scenes spread over the shard
+      (20 000 data points, about 2e9 samples: 15 s on the box's 16 cores), and the whole shard
       against the build that evaluates every sample in full (lib/libc2d_nopretest.so): the pretests and the
       compaction queue change no count at this size either;
   config 5: 1e7 polygon pairs — runs in tests/fullsize_poly_check.py (inputs are built with torch on the device).
@@ -49,12 +50,12 @@ def test_config4_shard_at_full_size(eng, pkg, oracle, wl):
     scenes = d_sc.get()
     rng = np.random.default_rng(4)
     checked = 0
-    for b in rng.integers(0, ns - 100, 20):
+    for b in rng.integers(0, ns - 100, 200):
         b = int(b)
         rh, ru, _, _ = oracle.mc_scenes(tp, ts, scenes[b:b + 100], 4.07, 1.74, [0, .01, .1, 1], [1e-4, 1e-3, 1e-2], 120_000, 11, b)
         assert np.array_equal(rh, h[b:b + 100]) and np.array_equal(ru, u[b:b + 100]), b
         checked += int(ru.astype(np.int64).sum())
-    assert checked > 2_000_000
+    assert checked > 1_000_000_000
     # the full-evaluation build on the whole shard
     full = pkg.Engine(0, lib_path=NOPRETEST)
     fh, fu, ft, _ = _scenes_run(full, pkg, d_p.ptr, d_s.ptr, d_sc.ptr, ns, 0)
