@@ -85,5 +85,7 @@ $(LIBDIR)/libc2d_mcstats.so: $(OBJS) $(CSRC)/c2d_mc_stats.o
 lib-mcclock: $(LIBDIR)/libc2d_mcclock.so
 $(CSRC)/c2d_mc_clock.o: $(CSRC)/c2d_mc.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -DC2D_MC_CLOCK -c $< -o $@
-$(LIBDIR)/libc2d_mcclock.so: $(OBJS) $(CSRC)/c2d_mc_clock.o
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(filter-out $(CSRC)/c2d_mc.o,$(OBJS)) $(CSRC)/c2d_mc_clock.o -ldl
+$(CSRC)/c2d_mc_poly_clock.o: $(CSRC)/c2d_mc_poly.hip $(HDRS)
+	$(HIPCC) $(HIPFLAGS) -DC2D_MC_CLOCK -c $< -o $@
+$(LIBDIR)/libc2d_mcclock.so: $(OBJS) $(CSRC)/c2d_mc_clock.o $(CSRC)/c2d_mc_poly_clock.o
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(filter-out $(CSRC)/c2d_mc.o $(CSRC)/c2d_mc_poly.o,$(OBJS)) $(CSRC)/c2d_mc_clock.o $(CSRC)/c2d_mc_poly_clock.o -ldl

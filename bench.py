@@ -575,6 +575,7 @@ def main() -> None:
             mc_poly["roofline"] = {"bound": "valu", "kernel": "mc_poly_pair_kernel", "achieved": round(lane_ops, 2), "peak": VALU_PEAK_TLANE,
                                    "unit": "T VALU lane-instr/s per GPU", "frac": round(lane_ops / VALU_PEAK_TLANE, 4),
                                    "valu_instr_per_sample": c["valu_instr_per_sample"], "instr_source": c.get("source")}
+            held_clock(mc_poly["roofline"], c)
 
     # ---- config 4: adaptive Monte-Carlo over many scenes -------------------------------------
     scenes_leg, scenes_keep = None, None

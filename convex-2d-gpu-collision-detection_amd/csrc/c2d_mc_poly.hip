@@ -421,6 +421,10 @@ struct PolyPairArgs {
 #ifndef C2D_MC_POLY_WAVES
 #define C2D_MC_POLY_WAVES 5
 #endif
+#ifdef C2D_MC_CLOCK
+C2D_MC_CLOCK_WORDS(c2d_mc_clock_poly_pair);  // clock build only (make lib-mcclock): read by c2d_debug_mc_poly_clock
+C2D_MC_CLOCK_WORDS(c2d_mc_clock_poly);
+#endif
 __global__ __launch_bounds__(kMcBlock, C2D_MC_POLY_WAVES) void mc_poly_pair_kernel(PolyPairArgs A, unsigned long long* __restrict__ d_hits)
 {
     __shared__ PolyQueue s_queue[kWavesPerBlock];
@@ -430,12 +434,14 @@ __global__ __launch_bounds__(kMcBlock, C2D_MC_POLY_WAVES) void mc_poly_pair_kern
                                           lane_pick(A.obstacle.y, l), (int)A.obstacle.k, A.sd, s_queue[wave]);
     const uint64_t n_chunks = (A.n_samples + A.chunk - 1) / A.chunk;
     unsigned long long total = 0;
+    C2D_MC_CLOCK_START();
     for (uint64_t ch = (uint64_t)blockIdx.x * kWavesPerBlock + wave; ch < n_chunks; ch += (uint64_t)gridDim.x * kWavesPerBlock) {
         const uint64_t off = ch * A.chunk;
         const uint64_t left = A.n_samples - off;
         const uint32_t count = left < A.chunk ? (uint32_t)left : A.chunk;
         total += wave_count_hits<PolyPolicy>(sc, A.seed, A.scene_id, A.sample_begin + off, count, s_queue[wave]);
     }
+    C2D_MC_CLOCK_STOP(c2d_mc_clock_poly_pair);
     if ((threadIdx.x & 63) == 0 && total) atomicAdd(d_hits, total);
 }
 
@@ -461,10 +467,6 @@ struct PolyScenesArgs {
     c2d_polygon robot;
     uint32_t* async_err;
 };
-
-#ifdef C2D_MC_CLOCK
-C2D_MC_CLOCK_WORDS(c2d_mc_clock_poly);   // (the polygon kernels are stamped too, for completeness; no reader yet)
-#endif
 
 struct PolyBuilder {
     using Args = PolyScenesArgs;
@@ -575,5 +577,24 @@ int c2d_mc_poly_scenes(c2d_ctx* ctx, const c2d_mc_poly_scenes_args* a, c2d_strea
         else hipLaunchKernelGGL(mc_poly_scenes_advance_kernel<false>, dim3(blocks), dim3(kMcBlock), 0, s, args);
     }, "c2d_mc_poly_scenes");
 }
+
+#ifdef C2D_MC_CLOCK
+// clock build only: the stamps of mc_poly_pair_kernel (which = 0) or of mc_poly_scenes_advance_kernel (1): shader cycles, 100 MHz ticks, waves
+int c2d_debug_mc_poly_clock(c2d_ctx* ctx, int which, unsigned long long out[4], int reset)
+{
+    if (!ctx || !out || which < 0 || which > 1) return C2D_ERR_INVALID_ARG;
+    DeviceGuard g(ctx->device);
+    C2D_HIP(ctx, hipDeviceSynchronize());
+    const unsigned long long zero[4] = {};
+    if (which == 0) {
+        C2D_HIP(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(c2d_mc_clock_poly_pair), 4 * sizeof(unsigned long long)));
+        if (reset) C2D_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c2d_mc_clock_poly_pair), zero, sizeof zero));
+    } else {
+        C2D_HIP(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(c2d_mc_clock_poly), 4 * sizeof(unsigned long long)));
+        if (reset) C2D_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c2d_mc_clock_poly), zero, sizeof zero));
+    }
+    return C2D_OK;
+}
+#endif
 
 }  // extern "C"

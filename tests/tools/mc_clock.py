@@ -21,9 +21,9 @@ wl = importlib.import_module("c2d_amd.workloads")
 LIB = os.path.join(ROOT, "convex-2d-gpu-collision-detection_amd", "lib", "libc2d_mcclock.so")
 
 
-def clock(eng, which, reset=True):
+def clock(eng, which, reset=True, poly=False):
     out = (C.c_ulonglong * 4)()
-    fn = eng.lib.c2d_debug_mc_clock
+    fn = eng.lib.c2d_debug_mc_poly_clock if poly else eng.lib.c2d_debug_mc_clock
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong), C.c_int]
     assert fn(eng.h, which, out, 1 if reset else 0) == 0
@@ -59,6 +59,15 @@ def main():
     c3 = clock(eng, 0)
     print(f"config 3 (mc_pair_kernel, 20 x 1e8 samples back to back): {c3['waves']} waves, {c3['shader_cycles']:.4g} shader cycles in "
           f"{c3['ticks_100MHz']:.4g} ticks of 100 MHz: the waves held {c3['ghz']:.3f} GHz")
+    ps = wl.mc_poly_pair_scene()
+    for _ in range(10):
+        eng.mc_poly_pair(ps["robot"], ps["pos"], ps["theta"], ps["obstacle"], ps["std_dev"], 1234, 0, 0, 100_000_000, d)
+    eng.synchronize()
+    clock(eng, 0, poly=True)
+    for _ in range(10):
+        eng.mc_poly_pair(ps["robot"], ps["pos"], ps["theta"], ps["obstacle"], ps["std_dev"], 1234, 0, 0, 100_000_000, d)
+    cp = clock(eng, 0, poly=True)
+    print(f"polygon bench scene (mc_poly_pair_kernel, 10 x 1e8 samples back to back): {cp['waves']} waves, held {cp['ghz']:.3f} GHz")
     c4 = scenes(eng, 4_000_000, 120_000)
     print(f"config 4 shard (mc_scenes_advance_kernel, 4e6 data points, max_samples 120 000): {c4['waves']} waves, held {c4['ghz']:.3f} GHz")
     cd = scenes(eng, 100_000, 4_020_000)
@@ -67,13 +76,13 @@ def main():
         tag = next((a for a in sys.argv[1:] if not a.startswith("--")), "")
         path = os.path.join(ROOT, "profiles", "measured_counts.json")
         cur = json.load(open(path))
-        for key, c in (("mc_pair.config3", c3), ("mc_scenes.config4", c4)):
+        for key, c in (("mc_pair.config3", c3), ("mc_poly_pair.bench", cp), ("mc_scenes.config4", c4)):
             if key in cur:
                 cur[key]["held_clock_ghz"] = round(c["ghz"], 3)
                 cur[key]["held_clock_source"] = ("tests/tools/mc_clock.py on the clock build (make lib-mcclock): s_memtime / s_memrealtime stamps around the "
                                                  "sample work of %d waves%s" % (c["waves"], (", " + tag) if tag else ""))
         json.dump(cur, open(path, "w"), indent=1)
-        print("recorded", {k: cur[k].get("held_clock_ghz") for k in ("mc_pair.config3", "mc_scenes.config4") if k in cur})
+        print("recorded", {k: cur[k].get("held_clock_ghz") for k in ("mc_pair.config3", "mc_poly_pair.bench", "mc_scenes.config4") if k in cur})
     eng.close()
 
 
