@@ -153,6 +153,28 @@ C2D_DEV PolyScene build_poly_scene(float rvx, float rvy, int ka, float px, float
     return sc;
 }
 
+// min / max of a running extreme and two new values.  The extremes of a rolled loop arrive through a phi, of which the compiler
+// cannot know that it is no signalling NaN, so that it canonicalises the value (v_max_f32 x, x) before every v_min / v_max: two
+// more instructions per projection in the loop over the robot's vertices, which is a fifth of a polygon evaluation.  A tame
+// scene has no NaN anywhere (and arithmetic never produces a signalling one), so there the instruction is written out; the
+// all-bit-patterns path keeps the builtins, whose result for quiet NaNs is the one the oracle's comparison loop gives.
+template <bool NANS>
+C2D_DEV float min3_(float a, float b, float c)
+{
+    if constexpr (NANS) return __builtin_fminf(__builtin_fminf(a, b), c);
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+template <bool NANS>
+C2D_DEV float max3_(float a, float b, float c)
+{
+    if constexpr (NANS) return __builtin_fmaxf(__builtin_fmaxf(a, b), c);
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // ---- evaluation of one sample per lane, in two stages.  Both build the sampled obstacle in registers (the oracle's
 // sample_polygon: scale, rotate, move — the same floats both times) and run the interval test of utils.cu:172-180 on true normals:
 //   stage A  the robot's ka normals (its own interval is wave-uniform): 4 kb instructions per normal;
@@ -226,22 +248,28 @@ C2D_DEV unsigned long long poly_stage_obstacle(const PolyScene& sc, const PolyQu
                 mx2[a] = __builtin_fmaxf(mx2[a], p);
             }
         }
-        {
-            const float2 v = q.rvert[0];
+        // the robot's vertices, two per step from one 16-byte LDS read, the next pair in flight while this one is used (slots at and
+        // above ka repeat vertex 0, which is neutral, so an odd count reads one slot more)
+        const float4* rv2 = reinterpret_cast<const float4*>(q.rvert);  // (x0, y0, x1, y1)
+        const int pairs = (ka + 1) >> 1;
+        float4 cur = rv2[0];
+        float4 nxt = rv2[pairs > 1 ? 1 : 0];
 #pragma unroll
-            for (int a = 0; a < G; a++) {
-                r0[a] = nx[a] * v.x + ny[a] * v.y;
-                mn1[a] = mx1[a] = r0[a];
-            }
+        for (int a = 0; a < G; a++) {
+            r0[a] = nx[a] * cur.x + ny[a] * cur.y;
+            const float p1 = nx[a] * cur.z + ny[a] * cur.w;
+            mn1[a] = __builtin_fminf(r0[a], p1);
+            mx1[a] = __builtin_fmaxf(r0[a], p1);
         }
 #pragma nounroll
-        for (int k = 1; k < ka; k++) {
-            const float2 v = q.rvert[k];
+        for (int j = 1; j < pairs; j++) {
+            cur = nxt;
+            nxt = rv2[j + 1 < pairs ? j + 1 : j];  // (the last step reads its own pair again)
 #pragma unroll
             for (int a = 0; a < G; a++) {
-                const float p = nx[a] * v.x + ny[a] * v.y;
-                mn1[a] = __builtin_fminf(mn1[a], p);
-                mx1[a] = __builtin_fmaxf(mx1[a], p);
+                const float p0 = nx[a] * cur.x + ny[a] * cur.y, p1 = nx[a] * cur.z + ny[a] * cur.w;
+                mn1[a] = min3_<NANS>(mn1[a], p0, p1);
+                mx1[a] = max3_<NANS>(mx1[a], p0, p1);
             }
         }
 #pragma unroll
