@@ -39,6 +39,7 @@ struct PolyScene {
 struct PolyQueue {
     float4 axis[KM];    // robot edge i: true normal (nx, ny), the robot's own interval [rmin, rmax] on it (utils.cu:176)
     float4 pre[KM];     // centre pretest on that normal: certain miss if T < plo or T > phi; .z = the robot's FIRST projection
+    float4 ctr[KM];     // what the centre pretest reads, in one piece: (nx, ny, plo, phi)
     float2 rvert[KM];   // robot vertices, placed
     float2 overt[KM];   // obstacle vertices in the obstacle frame
     // survivors of the first stage of an evaluation (no robot normal separates them), waiting for the second on 64 busy lanes
@@ -135,6 +136,7 @@ C2D_DEV PolyScene build_poly_scene(float rvx, float rvy, int ka, float px, float
     if (lane < KM) {
         q.axis[l] = make_float4(nx, ny, rmin, rmax);
         q.pre[l] = make_float4(plo, phi, p_first, 0.0f);
+        q.ctr[l] = make_float4(nx, ny, plo, phi);
     }
     wave_lds_sync();
     // ---- tame: every parameter finite and below 1e15 in magnitude (a NaN compares false)
@@ -359,9 +361,9 @@ struct PolyPolicy {
         bool miss = false;
 #pragma nounroll
         for (int i = 0; i < sc.ka; i++) {
-            const float4 A = q.axis[i], B = q.pre[i];
+            const float4 A = q.ctr[i];
             const float t = fma_(A.x, dx, A.y * dy);
-            miss |= (t > B.y) | (t < B.x);
+            miss |= (t > A.w) | (t < A.z);
         }
         miss_m = __builtin_amdgcn_ballot_w64(miss);
         return miss;
