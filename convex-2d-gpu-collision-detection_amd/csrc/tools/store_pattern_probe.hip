@@ -87,6 +87,29 @@ __global__ __launch_bounds__(512) void scatter_kernel(float* __restrict__ out, S
     }
 }
 
+// the store pattern of a sort that stages through a per-bin ring in LDS and only ever stores whole 64-byte sectors: a block owns a range
+// of `segs` tiles; for each plane and each tile, a group of 16 lanes takes bin b = group, group + 32, ... and stores the sectors of that
+// bin's row which the tile completes (the tile adds c slots to the bin; sector s is complete once slot 16 s + 15 has arrived)
+__global__ __launch_bounds__(512) void ring_kernel(float* __restrict__ out, Shape sh)
+{
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int t_first = (xcd * sh.tiles_per_xcd + idx) * sh.segs;
+    if (idx >= sh.tiles_per_xcd || t_first >= sh.T) return;
+    const int group = threadIdx.x >> 4, k = threadIdx.x & 15;
+    for (int plane = 0; plane < sh.RP; plane++)
+        for (int g = 0; g < sh.segs && t_first + g < sh.T; g++) {
+            const long long f0 = (long long)(t_first + g) * sh.c, f1 = f0 + sh.c;   // the tile's slots of every bin
+            // (the first tile of a range also owns the sector its first slot lies in, the last one the sector its last slot lies in:
+            //  range boundaries are the only shared sectors, and they are few)
+            const long long s0 = f0 >> 4, s1 = (g == sh.segs - 1 || t_first + g == sh.T - 1) ? ((f1 + 15) >> 4) : (f1 >> 4);
+            for (int b = group; b < sh.B; b += 32)
+                for (long long sec = s0; sec < s1; sec++) {
+                    const long long slot = sec * 16 + k;
+                    if (slot < sh.S64) out[element_of<false>(sh, b, plane, slot)] = (float)slot;
+                }
+        }
+}
+
 // the same bytes as one stream: every thread writes consecutive float4
 __global__ __launch_bounds__(512) void stream_kernel(float4* __restrict__ out, long long n4)
 {
@@ -232,6 +255,31 @@ int main()
         auto r = timed([&] { hipLaunchKernelGGL((scatter_kernel<false, false, false>), dim3(grid), dim3(512), 0, 0, d, sh); });
         printf("%-6d %-6d %-6d %-6d | %5d | %6d | %7.1f | %7.1f | %.2f\n", sh.B, sh.c, P, sh.segs, sh.c * 4, ranges, r.first * 1e3, r.second * 1e3,
                bytes / (r.first * 1e-3) / 1e12);
+        fflush(stdout);
+    }
+    // fourth table: whole-sector stores out of a ring (ring_kernel)
+    printf("\n%-6s %-6s %-6s %-6s | ranges | min us  | avg us  | TB/s   (ring: 16-lane groups store whole 64-byte sectors)\n", "bins", "c", "tile", "segs");
+    const int ring_list[][3] = {{196, 21, 10}, {196, 21, 5}, {196, 41, 5}, {196, 10, 20}, {49, 83, 10}};
+    for (auto& m : ring_list) {
+        Shape sh;
+        sh.B = m[0];
+        sh.c = m[1];
+        sh.segs = m[2];
+        sh.RP = RP;
+        sh.plain_map = 0;
+        const int P = sh.B * sh.c;
+        sh.T = (int)(N / P);
+        const int ranges = (sh.T + sh.segs - 1) / sh.segs;
+        sh.tiles_per_xcd = (ranges + 7) / 8;
+        const long long S = (long long)sh.T * sh.c;
+        sh.S64 = (S + 63) / 64 * 64;
+        sh.magic_c = 0;
+        const long long total_elems = (long long)sh.B * RP * sh.S64;
+        if (total_elems > cap_elems) { printf("%-6d %-6d skipped\n", sh.B, sh.c); continue; }
+        const long long bytes = (long long)sh.T * sh.B * sh.c * RP * 4;
+        const unsigned grid = 8u * (unsigned)sh.tiles_per_xcd;
+        auto r = timed([&] { hipLaunchKernelGGL(ring_kernel, dim3(grid), dim3(512), 0, 0, d, sh); });
+        printf("%-6d %-6d %-6d %-6d | %6d | %7.1f | %7.1f | %.2f\n", sh.B, sh.c, P, sh.segs, ranges, r.first * 1e3, r.second * 1e3, bytes / (r.first * 1e-3) / 1e12);
         fflush(stdout);
     }
     CHECK(hipFree(d));
