@@ -139,12 +139,16 @@ C2D_DEV PolyScene build_poly_scene(float rvx, float rvy, int ka, float px, float
         q.ctr[l] = make_float4(nx, ny, plo, phi);
     }
     wave_lds_sync();
-    // ---- tame: every parameter finite and below 1e15 in magnitude (a NaN compares false)
-    const float big = 1e15f;
-    auto ok = [big](float v) { return __builtin_fabsf(v) < big; };
-    const bool mine = ((int)l >= ka || (ok(rvx) && ok(rvy))) && ((int)l >= kb || (ok(ovx) && ok(ovy)));
-    const bool tame = __builtin_amdgcn_ballot_w64(!mine) == 0ull && ok(px) && ok(py) && ok(theta) && ok(sd.x) && ok(sd.y) && ok(sd.theta) && ok(sd.width) &&
-                      ok(sd.height);
+    // ---- tame: every parameter finite (a NaN compares false) and small enough for NO intermediate of an evaluation to overflow —
+    // the tame path's extremes are v_min / v_max, which agree with the comparison loop of minmax_element only where no NaN arises,
+    // and an inf - inf makes one.  Lengths (vertices, position, sigma_x, sigma_y) below 1e8 and relative shape deviations below 1e4:
+    // a scale factor stays below 7e4, a sampled coordinate below 1.4e13, a normal below 2.8e13, a projection below 1e27.
+    // Angles only pass through the sine and cosine.  Everything else takes one sample per lane with the all-bit-patterns test.
+    auto below = [](float v, float bound) { return __builtin_fabsf(v) < bound; };
+    const float len = 1e8f, rel = 1e4f, ang = 1e15f;
+    const bool mine = ((int)l >= ka || (below(rvx, len) && below(rvy, len))) && ((int)l >= kb || (below(ovx, len) && below(ovy, len)));
+    const bool tame = __builtin_amdgcn_ballot_w64(!mine) == 0ull && below(px, len) && below(py, len) && below(theta, ang) && below(sd.x, len) &&
+                      below(sd.y, len) && below(sd.theta, ang) && below(sd.width, rel) && below(sd.height, rel);
     sc.use_x0 = false;
     sc.x0 = 0xffffffffu;
     if (!tame) {

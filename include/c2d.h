@@ -421,8 +421,11 @@ int c2d_sample_scenes(c2d_ctx* ctx, const Pose* d_poses, uint32_t num_poses,
  * c2d_mc_pair gives it; the two tests then differ only in the scale of their axes (edge vector there,
  * normal here), which can move a boolean only for a sample within an ulp of touching.
  * Vertex order may be clockwise or counter-clockwise; 1 <= k <= C2D_POLY_KMAX (k = 1, 2: a point, a
- * segment).  The certain-miss shortcuts require finite parameters below 1e15 in magnitude, as for
- * c2d_mc_pair; outside that domain every sample is evaluated in full with the all-bit-patterns test. */
+ * segment).  The certain-miss shortcuts and the fast evaluation require finite parameters small enough
+ * for no intermediate to overflow: vertices, position, sigma_x, sigma_y below 1e8 in magnitude, the
+ * relative deviations sigma_w, sigma_h below 1e4 (a scale factor multiplies every coordinate), angles
+ * below 1e15; outside that domain every sample is evaluated in full with the all-bit-patterns test and
+ * the hit counts still equal the oracle's. */
 typedef struct c2d_polygon {
     uint32_t k;                   /* vertices used */
     float x[C2D_POLY_KMAX];

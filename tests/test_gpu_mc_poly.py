@@ -156,6 +156,29 @@ def test_mc_poly_pair_non_finite_scenes(eng, oracle, wl):
             assert got == ref, (i, got, ref)
 
 
+def test_mc_poly_pair_large_finite_scenes(eng, oracle, wl):
+    """finite parameters on both sides of the bounds below which the fast evaluation runs (lengths 1e8, relative shape deviations 1e4):
+    above them an intermediate can overflow, inf - inf makes a NaN, and only the all-bit-patterns path follows minmax_element there"""
+    sc = wl.mc_poly_pair_scene(6, 7)
+    rx, ry = sc["robot"]
+    ox, oy = sc["obstacle"]
+    cases = []
+    for scale in (3e6, 9e7, 1.1e8, 4e9, 3e13):       # the whole scene at another scale (shape noise off and on)
+        for sd in ((0.3 * scale, 0.3 * scale, 0.2, 0.0, 0.0), (0.3 * scale, 0.2 * scale, 0.2, 0.05, 0.1)):
+            cases.append(((rx * scale, ry * scale), (sc["pos"][0] * scale, sc["pos"][1] * scale), sc["theta"], (ox * scale, oy * scale), sd))
+    for sw in (3e3, 9.9e3, 1.1e4, 1e9, 5e14):        # huge relative shape deviations, scene at 1, 1e5 and 9e7
+        for scale in (1.0, 1e5, 9e7):
+            cases.append(((rx * scale, ry * scale), (sc["pos"][0] * scale, sc["pos"][1] * scale), sc["theta"], (ox * scale, oy * scale),
+                          (0.3 * scale, 0.3 * scale, 0.2, sw, 0.5 * sw)))
+    with np.errstate(all="ignore"):
+        for i, (robot, pos, theta, obstacle, sd) in enumerate(cases):
+            robot = tuple(np.asarray(a, np.float32) for a in robot)
+            obstacle = tuple(np.asarray(a, np.float32) for a in obstacle)
+            ref = oracle.mc_poly_pair(robot, pos, theta, obstacle, sd, 9, i, 1, 30_001)
+            got = gpu_hits(eng, robot, pos, theta, obstacle, sd, 9, i, 1, 30_001)
+            assert got == ref, (i, got, ref)
+
+
 def test_mc_poly_pair_argument_errors(eng, pkg, wl):
     sc = wl.mc_poly_pair_scene()
     d = eng.zeros(1, np.uint64)
