@@ -75,7 +75,7 @@ struct Scene {
     // Closed-form test of a full evaluation (model_gap): the robot as centre, rotation and half extents, and the margin
     // within which the closed form does not decide (+inf: never decides, every evaluation takes the vertex arithmetic)
     float mrx, mry, mcr, msr, mhw, mhh, margin;
-    // use_x0 == false && x0 == 0 marks a scene that is not "tame": some parameter is NaN, infinite or >= 1e15 in
+    // use_x0 == false && x0 == 0 marks a scene that is not "tame": some parameter is NaN, infinite, >= 1e15 or (a length) below 1e-15 in
     // magnitude, so a sampled vertex or a projection may be non-finite.  Such a scene takes wave_count_hits_plain: no
     // pretest (their proofs assume numbers) and the axis test that restores minmax_element's behaviour on a NaN first
     // projection (first_projections_ordered, c2d_math.hpp).  Below 1e15 no product on the way can overflow, so a tame
@@ -185,8 +185,11 @@ C2D_DEV Scene make_scene_values(float robot_w, float robot_h, float px, float py
     {
         const float big = 1e15f;  // (a NaN compares false: not tame)
         auto ok = [big](float v) { return __builtin_fabsf(v) < big; };
-        const bool tame = ok(robot_w) && ok(robot_h) && ok(px) && ok(py) && ok(pose.width) && ok(pose.height) && ok(pose.theta) &&
-                          ok(sd.x) && ok(sd.y) && ok(sd.theta) && ok(sd.width) && ok(sd.height);
+        // ... and no length so small that a product of two lengths leaves the normal range: the margins of the shortcuts are
+        // RELATIVE rounding bounds, which a denormal product does not obey (scenes scaled by 1e-22 differed from the oracle)
+        auto len = [big](float v) { const float a = __builtin_fabsf(v); return a < big && (a == 0.0f || a >= 1e-15f); };
+        const bool tame = len(robot_w) && len(robot_h) && len(px) && len(py) && len(pose.width) && len(pose.height) && ok(pose.theta) &&
+                          len(sd.x) && len(sd.y) && ok(sd.theta) && len(sd.width) && len(sd.height);
         if (!tame) {
             sc.x0 = 0u;  // the mark (see Scene::tame)
             return sc;

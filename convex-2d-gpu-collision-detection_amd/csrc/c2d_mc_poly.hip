@@ -144,11 +144,14 @@ C2D_DEV PolyScene build_poly_scene(float rvx, float rvy, int ka, float px, float
     // and an inf - inf makes one.  Lengths (vertices, position, sigma_x, sigma_y) below 1e8 and relative shape deviations below 1e4:
     // a scale factor stays below 7e4, a sampled coordinate below 1.4e13, a normal below 2.8e13, a projection below 1e27.
     // Angles only pass through the sine and cosine.  Everything else takes one sample per lane with the all-bit-patterns test.
+    // Nor may a nonzero length be so small that a product of two lengths leaves the normal range (below 1e-15): the margins of the
+    // pretest are relative rounding bounds, which a denormal product does not obey (scenes scaled by 1e-22 differed from the oracle).
     auto below = [](float v, float bound) { return __builtin_fabsf(v) < bound; };
-    const float len = 1e8f, rel = 1e4f, ang = 1e15f;
-    const bool mine = ((int)l >= ka || (below(rvx, len) && below(rvy, len))) && ((int)l >= kb || (below(ovx, len) && below(ovy, len)));
-    const bool tame = __builtin_amdgcn_ballot_w64(!mine) == 0ull && below(px, len) && below(py, len) && below(theta, ang) && below(sd.x, len) &&
-                      below(sd.y, len) && below(sd.theta, ang) && below(sd.width, rel) && below(sd.height, rel);
+    auto length = [](float v) { const float a = __builtin_fabsf(v); return a < 1e8f && (a == 0.0f || a >= 1e-15f); };
+    const float rel = 1e4f, ang = 1e15f;
+    const bool mine = ((int)l >= ka || (length(rvx) && length(rvy))) && ((int)l >= kb || (length(ovx) && length(ovy)));
+    const bool tame = __builtin_amdgcn_ballot_w64(!mine) == 0ull && length(px) && length(py) && below(theta, ang) && length(sd.x) && length(sd.y) &&
+                      below(sd.theta, ang) && below(sd.width, rel) && below(sd.height, rel);
     sc.use_x0 = false;
     sc.x0 = 0xffffffffu;
     if (!tame) {

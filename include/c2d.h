@@ -34,9 +34,11 @@
  * a later vertex is skipped; infinities are ordered like numbers.  Consequence: a pair with
  * a NaN in vertex 0 of either polygon reads "collide".  The Monte-Carlo entry points
  * (c2d_mc_pair, c2d_mc_scenes, c2d_sample_scenes) take table-driven scene parameters and
- * require them to be finite and below 1e15 in magnitude; outside that domain a call still
- * terminates and stays memory-safe, and its hit counts follow the same rules (every
- * certain-miss shortcut is switched off for such a scene).
+ * require them to be finite and below 1e15 in magnitude, and every length either zero or at
+ * least 1e-15 (a product of two smaller lengths is denormal, and the shortcuts' margins are
+ * relative rounding bounds); outside that domain a call still terminates and stays memory-safe,
+ * and its hit counts follow the same rules (every certain-miss shortcut is switched off for
+ * such a scene).
  */
 #ifndef C2D_H_
 #define C2D_H_
@@ -422,7 +424,8 @@ int c2d_sample_scenes(c2d_ctx* ctx, const Pose* d_poses, uint32_t num_poses,
  * normal here), which can move a boolean only for a sample within an ulp of touching.
  * Vertex order may be clockwise or counter-clockwise; 1 <= k <= C2D_POLY_KMAX (k = 1, 2: a point, a
  * segment).  The certain-miss shortcuts and the fast evaluation require finite parameters small enough
- * for no intermediate to overflow: vertices, position, sigma_x, sigma_y below 1e8 in magnitude, the
+ * for no intermediate to overflow or to turn denormal: vertices, position, sigma_x, sigma_y zero or
+ * between 1e-15 and 1e8 in magnitude, the
  * relative deviations sigma_w, sigma_h below 1e4 (a scale factor multiplies every coordinate), angles
  * below 1e15; outside that domain every sample is evaluated in full with the all-bit-patterns test and
  * the hit counts still equal the oracle's. */

@@ -310,6 +310,24 @@ def test_mc_pair_non_finite_scenes(eng, oracle, robot, pos, pose, sd):
         d.free()
 
 
+@pytest.mark.parametrize("exponent", [-10, -14, -16, -19, -21, -22, -23, -26, -30])
+def test_mc_pair_whole_scene_at_tiny_scales(eng, oracle, wl, exponent):
+    """The config-3 scene scaled down until products of two lengths are denormal: the shortcuts' margins are RELATIVE rounding
+    bounds, so a scene with a nonzero length below 1e-15 takes the plain path (at 1e-22 and 1e-23 the fast paths differed from
+    the oracle by up to 20 % of the hits)."""
+    sc = wl.MC_PAIR_SCENE
+    scale = 10.0 ** exponent
+    w, h = sc["robot_w"] * scale, sc["robot_h"] * scale
+    pos = (sc["pos"][0] * scale, sc["pos"][1] * scale)
+    pose = (sc["pose"][0] * scale, sc["pose"][1] * scale, sc["pose"][2])
+    for j, sd in enumerate(((0.3 * scale, 0.3 * scale, 0.2, 0.0, 0.0), (0.3 * scale, 0.3 * scale, 0.2, 0.05 * scale, 0.1 * scale), (3.0 * scale, 3.0 * scale, 0.2, 0.0, 0.0))):
+        d = eng.zeros(1, np.uint64)
+        eng.mc_pair(w, h, pos, pose, sd, 9, j, 1, 30_001, d)
+        with np.errstate(all="ignore"):
+            assert int(d.get()[0]) == oracle.mc_pair(w, h, pos, pose, sd, 9, j, 1, 30_001), (exponent, j)
+        d.free()
+
+
 def test_mc_scenes_with_non_finite_table_entries(eng, oracle, wl, pkg):
     """Adaptive loop over tables in which some poses / standard deviations are NaN, infinite or huge: those scenes take
     the plain path inside the same launches, the others are untouched; hits, sample counts and rows equal the oracle's."""

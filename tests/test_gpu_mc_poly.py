@@ -157,8 +157,8 @@ def test_mc_poly_pair_non_finite_scenes(eng, oracle, wl):
 
 
 def test_mc_poly_pair_large_finite_scenes(eng, oracle, wl):
-    """finite parameters on both sides of the bounds below which the fast evaluation runs (lengths 1e8, relative shape deviations 1e4):
-    above them an intermediate can overflow, inf - inf makes a NaN, and only the all-bit-patterns path follows minmax_element there"""
+    """finite parameters on both sides of the bounds within which the fast evaluation runs (lengths 1e-15 .. 1e8, relative shape deviations
+    below 1e4): above them an intermediate can overflow, inf - inf makes a NaN, and only the all-bit-patterns path follows minmax_element there"""
     sc = wl.mc_poly_pair_scene(6, 7)
     rx, ry = sc["robot"]
     ox, oy = sc["obstacle"]
@@ -170,6 +170,10 @@ def test_mc_poly_pair_large_finite_scenes(eng, oracle, wl):
         for scale in (1.0, 1e5, 9e7):
             cases.append(((rx * scale, ry * scale), (sc["pos"][0] * scale, sc["pos"][1] * scale), sc["theta"], (ox * scale, oy * scale),
                           (0.3 * scale, 0.3 * scale, 0.2, sw, 0.5 * sw)))
+    for e in (-14, -16, -19, -21, -22, -23, -26, -30):  # and whole scenes so small that products of two lengths are denormal: the pretest's margins
+        scale = 10.0 ** e                                # are relative rounding bounds (scenes at 1e-22 and 1e-23 differed before lengths below 1e-15 left the fast path)
+        for sd in ((0.3 * scale, 0.3 * scale, 0.2, 0.0, 0.0), (3.0 * scale, 3.0 * scale, 0.2, 0.05, 0.1)):
+            cases.append(((rx * scale, ry * scale), (sc["pos"][0] * scale, sc["pos"][1] * scale), sc["theta"], (ox * scale, oy * scale), sd))
     with np.errstate(all="ignore"):
         for i, (robot, pos, theta, obstacle, sd) in enumerate(cases):
             robot = tuple(np.asarray(a, np.float32) for a in robot)
