@@ -75,6 +75,8 @@ def test_mc_poly_pair_sample_ranges_add_up(eng, oracle, wl):
     for a, b in zip(cuts, cuts[1:]):  # accumulating into one counter
         eng.mc_poly_pair(*args[:5], 1234, 0, a, b - a, d)
     assert int(d.get()[0]) == whole
+    for begin, n in (((1 << 40) + 3, 20_047), ((1 << 32) - 5, 4_099), ((1 << 61) + 1, 777)):  # sample indices beyond 32 bits, ranges that straddle 2^32
+        assert gpu_hits(eng, *args, begin, n) == oracle.mc_poly_pair(*args, begin, n), begin
 
 
 def test_rectangles_as_polygons_reproduce_mc_pair(eng, oracle, wl):
