@@ -28,7 +28,8 @@ def one(eng, rng, idx):
     rw, rh = float(rng.uniform(0.5, 5)), float(rng.uniform(0.5, 3))
     spread = float(rng.choice([0.5, 2.0, 4.0, 8.0]))
     if rng.random() < 0.3:  # the whole scene at another scale, or the obstacles as slivers: the closed-form evaluation's margins scale with both
-        k = np.float32(10.0 ** int(rng.integers(-9, 10)))
+        # (one scene in five of these far out: denormal products below, the edge of the fast paths' domain above)
+        k = np.float32(10.0 ** int(rng.integers(-9, 10) if rng.random() < 0.8 else rng.choice([-30, -26, -23, -22, -21, -19, -16, -14, 12, 14])))
         tp, ts = tp.copy(), ts.copy()
         sliver = np.float32(1e-4) if rng.random() < 0.3 else np.float32(1.0)
         tp["width"] *= k

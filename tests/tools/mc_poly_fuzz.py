@@ -35,7 +35,8 @@ def one(eng, rng, idx):
         robot = (robot[0], (robot[1] * np.float32(1e-4)).astype(np.float32))
     scale = np.float32(1.0)
     if rng.random() < 0.3:  # the whole scene at another scale
-        scale = np.float32(10.0 ** int(rng.integers(-6, 7)))
+        # (one scene in five of these far out: denormal products below, the edge of the fast paths' domain above)
+        scale = np.float32(10.0 ** int(rng.integers(-6, 7) if rng.random() < 0.8 else rng.choice([-30, -26, -23, -22, -21, -19, -16, -14, 7, 8, 11])))
         poses, sds = poses.copy(), sds.copy()
         poses["obstacle"]["x"] *= scale
         poses["obstacle"]["y"] *= scale
