@@ -110,6 +110,20 @@ __global__ __launch_bounds__(512) void ring_kernel(float* __restrict__ out, Shap
         }
 }
 
+// unaligned runs as in scatter_kernel (SoA, plane-outer), but a run is never cut between two waves: wave w stores the runs w, w + 8, ...
+// with its first c lanes (c <= 64)
+__global__ __launch_bounds__(512) void run_per_wave_kernel(float* __restrict__ out, Shape sh)
+{
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int t = xcd * sh.tiles_per_xcd + idx;
+    if (idx >= sh.tiles_per_xcd || t >= sh.T) return;
+    const long long slot0 = (long long)t * sh.c;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int plane = 0; plane < sh.RP; plane++)
+        for (int b = wave; b < sh.B; b += 8)
+            if (lane < sh.c) out[element_of<false>(sh, b, plane, slot0 + lane)] = (float)lane;
+}
+
 // the same bytes as one stream: every thread writes consecutive float4
 __global__ __launch_bounds__(512) void stream_kernel(float4* __restrict__ out, long long n4)
 {
@@ -256,6 +270,22 @@ int main()
         printf("%-6d %-6d %-6d %-6d | %5d | %6d | %7.1f | %7.1f | %.2f\n", sh.B, sh.c, P, sh.segs, sh.c * 4, ranges, r.first * 1e3, r.second * 1e3,
                bytes / (r.first * 1e-3) / 1e12);
         fflush(stdout);
+    }
+    // a run per wave: does it matter that scatter_kernel cuts runs at wave boundaries?
+    {
+        Shape sh;
+        sh.B = 196; sh.c = 41; sh.RP = RP; sh.segs = 0; sh.plain_map = 0;
+        sh.T = (int)(N / (sh.B * sh.c));
+        sh.tiles_per_xcd = (sh.T + 7) / 8;
+        const long long S = (long long)sh.T * sh.c;
+        sh.S64 = (S + 63) / 64 * 64;
+        sh.magic_c = (unsigned)(((1ull << 32) + sh.c - 1) / sh.c);
+        const long long bytes = (long long)sh.T * sh.B * sh.c * RP * 4;
+        const unsigned grid = 8u * (unsigned)sh.tiles_per_xcd;
+        auto r0 = timed([&] { hipLaunchKernelGGL((scatter_kernel<false, false, false>), dim3(grid), dim3(512), 0, 0, d, sh); });
+        auto r1 = timed([&] { hipLaunchKernelGGL(run_per_wave_kernel, dim3(grid), dim3(512), 0, 0, d, sh); });
+        printf("\n196 bins, c = 41: runs cut at wave boundaries %.1f us, one run per wave %.1f us (%.2f / %.2f TB/s)\n", r0.first * 1e3, r1.first * 1e3,
+               bytes / (r0.first * 1e-3) / 1e12, bytes / (r1.first * 1e-3) / 1e12);
     }
     // fourth table: whole-sector stores out of a ring (ring_kernel)
     printf("\n%-6s %-6s %-6s %-6s | ranges | min us  | avg us  | TB/s   (ring: 16-lane groups store whole 64-byte sectors)\n", "bins", "c", "tile", "segs");
