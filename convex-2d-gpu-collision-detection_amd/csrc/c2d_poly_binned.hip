@@ -509,8 +509,10 @@ struct BinMoveArgs {
 //    arbitrary 4-byte offset costs 2-3 times as much whatever the layout or the order — the 64-byte sectors at the two ends of a run are
 //    shared with the neighbouring tiles' runs, which other blocks write tens of microseconds earlier or later, and a tile contributes
 //    42 +- 6 pairs to a bin's row.  Hence the longer run per (tile, bin, row) is worth more than the second block per CU that a
-//    4096-pair tile allows (same box: 1.27 -> 1.15 ms; whole call 1.70 -> 1.38 ms); profiles/notes_r04_bin_move.md lists what would
-//    remove the shared sectors (an LDS carry per write front across the tiles of one block) and why it was not built.
+//    4096-pair tile allows (same box: 1.27 -> 1.15 ms; whole call 1.70 -> 1.38 ms).  The form that removes the shared sectors — a ring
+//    per bin in LDS that carries every write front's unfinished line from tile to tile, whole lines stored — was built and measured:
+//    correct, 1.29 ms at best against 1.03-1.11 ms for this one; its 640 small steps per block cost more than the stores save
+//    (profiles/notes_r04_bin_move.md, profiles/r04_ring_move_kernel.patch).
 typedef float v4f_u __attribute__((ext_vector_type(4), aligned(4)));  // four floats at any 4-byte boundary (a row of the padded batch starts anywhere)
 #ifndef C2D_MOVE_PRODUCER_WAVES
 #define C2D_MOVE_PRODUCER_WAVES 8
