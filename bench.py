@@ -156,6 +156,7 @@ def main() -> None:
     ap.add_argument("--prewarm-ms", type=float, default=150.0,
                     help="untimed device wake-up before the W warm-up steps: the first ~15 ms of load after idle run "
                          "up to 12 %% slower while the power manager ramps clocks (profiles/r01a trace)")
+    ap.add_argument("--poly-scenes", type=int, default=200_000, help="scenes per GPU of the adaptive polygon Monte-Carlo sub-leg (0 = skip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for rendezvous / barriers; nccl (= RCCL over xGMI) is the measured path, gloo only "
                          "rehearses the N > 1 code path on a box with fewer GPUs than ranks (together with --share-device; the "
@@ -576,6 +577,37 @@ def main() -> None:
                                    "unit": "T VALU lane-instr/s per GPU", "frac": round(lane_ops / VALU_PEAK_TLANE, 4),
                                    "valu_instr_per_sample": c["valu_instr_per_sample"], "instr_source": c.get("source")}
             held_clock(mc_poly["roofline"], c)
+        # the adaptive loop over a dataset of polygon scenes (c2d_mc_poly_scenes): random obstacle polygons of 3..16 vertices, a 9-gon
+        # robot, the stop rule of config 4.  Scenes shard over ranks like config 4's (scene_id_base = the shard's first scene).
+        PN = args.poly_scenes
+        if PN > 0:
+            pp_tab, ps_tab = wl.random_poly_tables(4096, 4096, seed=7)
+            p_scn = wl.random_poly_scenes(PN * world, pp_tab, ps_tab, 2.3, seed=8)[rank * PN:(rank + 1) * PN]
+            p_rob9 = wl.mc_poly_pair_scene(9, 5)["robot"]
+            d_pp, d_ps, d_pscn = eng.to_device(pp_tab), eng.to_device(ps_tab), eng.to_device(p_scn)
+            d_ph, d_pu = eng.zeros(PN, np.uint32), eng.zeros(PN, np.uint32)
+
+            def poly_scenes_step():
+                return eng.mc_poly_scenes(p_rob9, d_pp, len(pp_tab), d_ps, len(ps_tab), d_pscn, PN, wl.DEFAULT_BINS, wl.DEFAULT_BIN_ACCURACY, 120_000, 11,
+                                          rank * PN, d_ph, d_pu, None, stream=sh)
+
+            poly_scenes_step()  # warm (clocks, allocations of the schedule's lists)
+            torch.cuda.synchronize()
+            barrier()
+            pq0 = time.perf_counter()
+            p_total, p_iters = poly_scenes_step()
+            torch.cuda.synchronize()
+            barrier()
+            pqel = shd.max_over_ranks(time.perf_counter() - pq0, dev)
+            p_tot_t = torch.tensor([p_total], dtype=torch.int64, device=dev)
+            all_reduce_sum(p_tot_t)
+            torch.cuda.synchronize()
+            mc_poly["scenes"] = {"metric": "mc_poly_scenes_per_s", "value": PN * world / pqel, "scenes_per_gpu": PN, "max_samples": 120_000, "seconds": round(pqel, 4),
+                                 "drawn_samples_per_s": int(p_tot_t.item()) / pqel, "mean_samples_per_scene": int(p_tot_t.item()) / (PN * world), "steps": p_iters,
+                                 "workload": "4096 random obstacle polygons (3..16 vertices) x 4096 standard deviations, 9-gon robot, adaptive stopping as config 4"}
+            mc_poly_scenes_keep = (pp_tab, ps_tab, p_scn, p_rob9, d_ph.get(), d_pu.get(), rank * PN)
+            for a_ in (d_pp, d_ps, d_pscn, d_ph, d_pu):
+                a_.free()
 
     # ---- config 4: adaptive Monte-Carlo over many scenes -------------------------------------
     scenes_leg, scenes_keep = None, None
@@ -881,6 +913,23 @@ def main() -> None:
             mc_poly["cpu_baseline"] = {"value": done / cel, "unit": "samples/s", "cores": oracle.num_threads(), "kind": "port",
                                        "sample": f"first {done} samples of the same stream ({cel:.1f} s), OpenMP", "probability": h / done,
                                        "parity": mc_poly["parity"]}
+        if mc_poly is not None and "scenes" in mc_poly:  # its adaptive dataset: the first scenes of the shard, hits and stop points, then the oracle's rate
+            pp_tab, ps_tab, p_scn, p_rob9, g_h, g_u, base0 = mc_poly_scenes_keep
+            chk, done_s, smp = 0, 0, 0
+            c0 = time.perf_counter()
+            while chk < len(p_scn):
+                m = min(500, len(p_scn) - chk)
+                rh, ru, _, rt = oracle.mc_poly_scenes(p_rob9, pp_tab, ps_tab, p_scn[chk:chk + m], wl.DEFAULT_BINS, wl.DEFAULT_BIN_ACCURACY, 120_000, 11, base0 + chk)
+                if not (np.array_equal(rh, g_h[chk:chk + m]) and np.array_equal(ru, g_u[chk:chk + m])):
+                    raise SystemExit(f"PARITY FAILURE: adaptive polygon scenes {chk}..{chk + m}: hit or sample counts differ from the CPU oracle")
+                chk += m
+                smp += int(rt)
+                if time.perf_counter() - c0 >= budget:
+                    break
+            cel = time.perf_counter() - c0
+            mc_poly["scenes"]["parity"] = f"hits and sample counts equal on {chk} of {chk} scenes checked"
+            mc_poly["scenes"]["cpu_baseline"] = {"value": chk / cel, "unit": "scenes/s", "samples_per_s": smp / cel, "cores": oracle.num_threads(), "kind": "port",
+                                                 "sample": f"first {chk} scenes of the shard ({smp} samples, {cel:.1f} s), OpenMP over scenes", "parity": mc_poly["scenes"]["parity"]}
         if poly_keep is not None:  # config 5: every boolean of the 16-row batch
             hvx, hvy, hk, hout = poly_keep
             ref, ref_cnt = oracle.sat_poly_pairs(hvx, hvy, hk)

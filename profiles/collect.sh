@@ -8,7 +8,7 @@ R=$PWD
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 export TMPDIR=/tmp
-SMALL="--steps 20 --warmup 2 --prewarm-ms 0 --no-cpu-baseline --mc-reps 2 --poly-reps 3"
+SMALL="--steps 20 --warmup 2 --prewarm-ms 0 --no-cpu-baseline --mc-reps 2 --poly-reps 3 --poly-scenes 0"
 cd /tmp
 echo "== un-profiled bench"; timeout -k 10 500 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 echo "== kernel trace + stats"; timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err

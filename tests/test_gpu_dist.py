@@ -181,7 +181,7 @@ def test_bench_starts_its_own_ranks(tmp_path):
     """`python bench.py --gpus N` without a launcher (how the round-end driver calls it): rehearsed with two ranks
     sharing the device (gloo rendezvous + file transport), and with one rank through the real RCCL reduce."""
     small = ["--steps", "3", "--warmup", "1", "--pairs", "1000000", "--mc-samples", "1000000", "--mc-reps", "1", "--scenes", "20000",
-             "--scenes-max-samples", "3000", "--poly-pairs", "200000", "--poly-reps", "2", "--no-cpu-baseline", "--prewarm-ms", "5"]
+             "--scenes-max-samples", "3000", "--poly-pairs", "200000", "--poly-reps", "2", "--poly-scenes", "20000", "--no-cpu-baseline", "--prewarm-ms", "5"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--backend", "gloo"] + small,
                          capture_output=True, text=True, timeout=900, env=env)
@@ -331,7 +331,7 @@ def test_rccl_with_two_real_ranks_when_two_gpus_are_visible(tmp_path):
     if _visible_gpus() < 2:
         pytest.skip("needs two visible GPUs (RCCL refuses two ranks on one device)")
     small = ["--steps", "3", "--warmup", "1", "--pairs", "1000000", "--mc-samples", "1000000", "--mc-reps", "1", "--scenes", "20000",
-             "--scenes-max-samples", "3000", "--poly-pairs", "200000", "--poly-reps", "2", "--no-cpu-baseline", "--prewarm-ms", "5"]
+             "--scenes-max-samples", "3000", "--poly-pairs", "200000", "--poly-reps", "2", "--poly-scenes", "20000", "--no-cpu-baseline", "--prewarm-ms", "5"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + small, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
