@@ -605,6 +605,13 @@ def main() -> None:
             mc_poly["scenes"] = {"metric": "mc_poly_scenes_per_s", "value": PN * world / pqel, "scenes_per_gpu": PN, "max_samples": 120_000, "seconds": round(pqel, 4),
                                  "drawn_samples_per_s": int(p_tot_t.item()) / pqel, "mean_samples_per_scene": int(p_tot_t.item()) / (PN * world), "steps": p_iters,
                                  "workload": "4096 random obstacle polygons (3..16 vertices) x 4096 standard deviations, 9-gon robot, adaptive stopping as config 4"}
+            cq = counts.get("mc_poly_scenes.bench")
+            if cq and cq.get("scenes") == PN and cq.get("max_samples") == 120_000:
+                lane_ops = p_total / pqel * cq["valu_instr_per_sample"] / 1e12   # (this rank's drawn samples over the slowest rank's time)
+                mc_poly["scenes"]["roofline"] = {"bound": "valu", "kernel": "mc_poly_scenes_advance_kernel (all schedule steps)", "achieved": round(lane_ops, 2),
+                                                 "peak": VALU_PEAK_TLANE, "unit": "T VALU lane-instr/s per GPU", "frac": round(lane_ops / VALU_PEAK_TLANE, 4),
+                                                 "valu_instr_per_sample": cq["valu_instr_per_sample"], "instr_source": cq.get("source"),
+                                                 "note": "instructions per DRAWN sample, as for config 4"}
             mc_poly_scenes_keep = (pp_tab, ps_tab, p_scn, p_rob9, d_ph.get(), d_pu.get(), rank * PN)
             for a_ in (d_pp, d_ps, d_pscn, d_ph, d_pu):
                 a_.free()

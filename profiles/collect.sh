@@ -14,7 +14,7 @@ echo "== un-profiled bench"; timeout -k 10 500 python3 $R/bench.py > $O/bench.js
 echo "== kernel trace + stats"; timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
 echo "== pmc FETCH_SIZE"; timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py $SMALL --no-mc --scenes 0 > /dev/null 2> $O/pmc_fetch.err
 echo "== pmc WRITE_SIZE"; timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py $SMALL --no-mc --scenes 0 > /dev/null 2> $O/pmc_write.err
-echo "== pmc SQ"; timeout -k 10 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -- python3 $R/bench.py $SMALL > /dev/null 2> $O/pmc_sq.err
+echo "== pmc SQ"; timeout -k 10 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -- python3 $R/bench.py $SMALL --poly-scenes 200000 > /dev/null 2> $O/pmc_sq.err
 echo "== pmc SQ LDS (polygon kernel)"; timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_lds -- python3 $R/bench.py $SMALL --no-mc --no-pose --scenes 0 > /dev/null 2> $O/pmc_lds.err
 echo "== adaptive-loop trace (reference-default batch)"; timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $O/scenes_trace -- python3 $R/convex-2d-gpu-collision-detection_amd/csrc/tools/scenes_trace.py run $O/scenes > $O/scenes_run.txt 2> $O/scenes.err
 cd $R
