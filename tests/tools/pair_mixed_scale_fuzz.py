@@ -47,7 +47,12 @@ eng.sat_rect_pairs_pose(d_pp, n, d_out)
 got_p = d_out.get()
 eng.sat_rect_pairs_verts(d_pl, n, d_out)
 got_v = d_out.get()
-print(f"rectangles, {n} pairs ({cv} colliding): pose format differs on {int((got_p != ref_p).sum())}, vertex format on {int((got_v != ref_v).sum())}")
+d_mask = eng.zeros((n + 63) // 64, np.uint64)
+eng.sat_rect_pairs_verts_mask(d_pl, n, d_mask)
+bits = np.unpackbits(d_mask.get().view(np.uint8), bitorder="little")[:n]
+print(f"rectangles, {n} pairs ({cv} colliding): pose format differs on {int((got_p != ref_p).sum())}, vertex format on {int((got_v != ref_v).sum())}, "
+      f"bit-mask output on {int((bits != ref_v).sum())}")
+d_mask.free()
 for a in d_pp + d_pl + [d_out]:
     a.free()
 
@@ -76,3 +81,24 @@ bins.results(d_bo)
 got_b = d_bo.get()
 bins.close()
 print(f"polygons, {m} pairs ({c} colliding): padded layout differs on {int((got != ref).sum())}, binned batch on {int((got_b != ref).sum())}")
+for a in (dvx, dvy, dk, d_out, d_bo):
+    a.free()
+
+# ---- triangles and quadrilaterals in the 4-row layout (its own kernel)
+vx4, vy4, k4 = wl.random_convex_polygons(m, seed=seed + 2, kmin=1, kmax=4, extent=1.0, rows=4)
+sa, sb, so = scales(m), scales(m), scales(m)
+so = np.where(rng.random(m) < 0.5, np.maximum(sa, sb), so).astype(np.float32)
+for p, s_ in ((0, sa), (1, sb)):
+    x0, y0 = vx4[p][0].copy(), vy4[p][0].copy()
+    vx4[p] = (vx4[p] - x0) * s_
+    vy4[p] = (vy4[p] - y0) * s_
+off = (rng.uniform(-2, 2, (2, m)) * so).astype(np.float32)
+vx4[1] += off[0]; vy4[1] += off[1]
+vx4, vy4 = np.ascontiguousarray(vx4, np.float32), np.ascontiguousarray(vy4, np.float32)
+with np.errstate(all="ignore"):
+    pad = lambda a: np.concatenate([a, np.zeros((2, 12, m), np.float32)], axis=1)
+    ref4, c4 = oracle.sat_poly_pairs(pad(vx4), pad(vy4), k4)
+dvx, dvy, dk = eng.to_device(vx4), eng.to_device(vy4), eng.to_device(k4)
+d_out = eng.zeros(m, np.uint8)
+eng.sat_poly_pairs_rows(dvx, dvy, dk, m, 4, d_out)
+print(f"4-row polygons, {m} pairs ({c4} colliding): differ on {int((d_out.get() != ref4).sum())}")
