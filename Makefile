@@ -77,8 +77,10 @@ $(REHDIR)/libc2d.so: $(OBJS) $(CSRC)/c2d_dist_rehearsal.o
 lib-mcstats: $(LIBDIR)/libc2d_mcstats.so
 $(CSRC)/c2d_mc_stats.o: $(CSRC)/c2d_mc.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -DC2D_MC_STATS -c $< -o $@
-$(LIBDIR)/libc2d_mcstats.so: $(OBJS) $(CSRC)/c2d_mc_stats.o
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(filter-out $(CSRC)/c2d_mc.o,$(OBJS)) $(CSRC)/c2d_mc_stats.o -ldl
+$(CSRC)/c2d_mc_poly_stats.o: $(CSRC)/c2d_mc_poly.hip $(HDRS)
+	$(HIPCC) $(HIPFLAGS) -DC2D_MC_STATS -c $< -o $@
+$(LIBDIR)/libc2d_mcstats.so: $(OBJS) $(CSRC)/c2d_mc_stats.o $(CSRC)/c2d_mc_poly_stats.o
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(filter-out $(CSRC)/c2d_mc.o $(CSRC)/c2d_mc_poly.o,$(OBJS)) $(CSRC)/c2d_mc_stats.o $(CSRC)/c2d_mc_poly_stats.o -ldl
 
 # clock build (developer tool, not part of `all`): Monte-Carlo kernels that stamp s_memtime / s_memrealtime around their sample work
 # (C2D_MC_CLOCK in c2d_mc_core.hpp); tests/tools/mc_clock.py reads the stamps and records the clock the kernels hold

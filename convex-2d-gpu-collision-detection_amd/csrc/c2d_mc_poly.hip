@@ -18,6 +18,20 @@
 
 #include "c2d_internal.hpp"
 #include "c2d_math.hpp"
+
+// ---- census build (-DC2D_MC_STATS, `make lib-mcstats`; never the product), as in c2d_mc.hip: words 0-4 and 7 are the sample loops'
+// (samples, far path, near path, radius candidates, centres evaluated, hits); here [5] samples that reach the evaluation, [6] of
+// those the survivors of the robot's normals, [8] samples whose obstacle normals ran in place, [9] ... out of the survivor queue.
+#ifdef C2D_MC_STATS
+namespace c2d {
+__device__ unsigned long long c2d_mc_poly_stats_words[12];
+}
+#define C2D_MC_STAT(i, v)                                                                                     \
+    do {                                                                                                      \
+        const unsigned long long v__ = (unsigned long long)(v);                                               \
+        if ((threadIdx.x & 63) == 0 && v__) atomicAdd(&c2d::c2d_mc_poly_stats_words[i], v__);                 \
+    } while (0)
+#endif
 #include "c2d_mc_core.hpp"
 
 namespace c2d {
@@ -316,6 +330,7 @@ C2D_DEV unsigned long long poly_sample_stage(const PolyScene& sc, const PolyQueu
     }
     if constexpr (STAGE == 1) {
         if (__popcll(alive) < C2D_MC_POLY_IN_PLACE) { final = false; return alive; }
+        C2D_MC_STAT(8, __popcll(alive));
     }
     return poly_stage_obstacle<CB, NANS>(sc, q, ox, oy, alive);
 }
@@ -387,6 +402,7 @@ struct PolyPolicy {
         wave_lds_sync();
         n -= take;
         bool final;
+        C2D_MC_STAT(9, take);
         return (uint32_t)__popcll(poly_sample_stage_any<false, 2>(sc, q, a.x, a.y, a.z, a.w, b.x, b.y, live_m, final));
     }
     static C2D_DEV uint32_t evaluate(const Scene& sc, Queue& q, uint32_t w2r, uint32_t w2a, float dx, float dy, uint64_t seed, uint64_t scene_id, uint64_t sample,
@@ -395,8 +411,10 @@ struct PolyPolicy {
         float c, s, fx, fy;
         poly_sample_shape(sc, w2r, w2a, seed, scene_id, sample, c, s, fx, fy);
         bool final;
+        C2D_MC_STAT(5, __popcll(live_m));
         const unsigned long long alive = poly_sample_stage_any<false, 1>(sc, q, dx, dy, c, s, fx, fy, live_m, final);
         if (final) return (uint32_t)__popcll(alive);  // (nothing survived stage A, or stage B ran in place)
+        C2D_MC_STAT(6, __popcll(alive));
         uint32_t n = q.n_surv;  // (wave-uniform: every lane reads the same word)
         if ((alive >> (threadIdx.x & 63)) & 1ull) {
             const uint32_t slot = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(alive >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)alive, 0u));
@@ -614,6 +632,22 @@ int c2d_mc_poly_scenes(c2d_ctx* ctx, const c2d_mc_poly_scenes_args* a, c2d_strea
         else hipLaunchKernelGGL(mc_poly_scenes_advance_kernel<false>, dim3(blocks), dim3(kMcBlock), 0, s, args);
     }, "c2d_mc_poly_scenes");
 }
+
+#ifdef C2D_MC_STATS
+// census build only: copies the twelve counters to the host (after synchronising the device) and optionally clears them
+int c2d_debug_mc_poly_stats(c2d_ctx* ctx, unsigned long long out[12], int reset)
+{
+    if (!ctx || !out) return C2D_ERR_INVALID_ARG;
+    DeviceGuard g(ctx->device);
+    C2D_HIP(ctx, hipDeviceSynchronize());
+    C2D_HIP(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(c2d_mc_poly_stats_words), 12 * sizeof(unsigned long long)));
+    if (reset) {
+        const unsigned long long zero[12] = {};
+        C2D_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c2d_mc_poly_stats_words), zero, sizeof zero));
+    }
+    return C2D_OK;
+}
+#endif
 
 #ifdef C2D_MC_CLOCK
 // clock build only: the stamps of mc_poly_pair_kernel (which = 0) or of mc_poly_scenes_advance_kernel (1): shader cycles, 100 MHz ticks, waves

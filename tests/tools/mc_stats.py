@@ -57,6 +57,50 @@ def scenes(eng, ns, max_samples):
     return st
 
 
+POLY_NAMES = ["samples", "far_path", "near_path", "radius_candidates", "centres_evaluated", "evaluated", "survive_robot_normals_queued", "hits",
+              "obstacle_normals_in_place", "obstacle_normals_from_queue", "unused10", "unused11"]
+
+
+def poly_stats(eng, reset=True):
+    out = (C.c_ulonglong * 12)()
+    fn = eng.lib.c2d_debug_mc_poly_stats
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
+    assert fn(eng.h, out, 1 if reset else 0) == 0
+    return dict(zip(POLY_NAMES, [int(v) for v in out]))
+
+
+def poly_show(title, st):
+    n, ev = st["samples"], max(st["evaluated"], 1)
+    print(f"{title}: {n:.4g} samples; far path {st['far_path'] / n:.3f}, near path {st['near_path'] / n:.3f}; radius candidates (far) "
+          f"{st['radius_candidates'] / max(st['far_path'], 1):.5f} of the far samples; centres evaluated {st['centres_evaluated'] / n:.4f}; "
+          f"reach the evaluation {st['evaluated'] / n:.5f}; hits {st['hits'] / n:.5f} (= {st['hits'] / ev:.3f} of the evaluated); of the evaluated: "
+          f"obstacle normals in place {st['obstacle_normals_in_place'] / ev:.3f}, survivors of the robot's normals queued {st['survive_robot_normals_queued'] / ev:.3f} "
+          f"(evaluated from the queue {st['obstacle_normals_from_queue'] / ev:.3f}), decided by the robot's normals alone "
+          f"{1 - (st['obstacle_normals_in_place'] + st['survive_robot_normals_queued']) / ev:.3f}")
+
+
+def poly_main(eng):
+    ps = wl.mc_poly_pair_scene()
+    d = eng.zeros(1, np.uint64)
+    poly_stats(eng)
+    eng.mc_poly_pair(ps["robot"], ps["pos"], ps["theta"], ps["obstacle"], ps["std_dev"], 1234, 0, 0, 100_000_000, d)
+    st = poly_stats(eng)
+    assert st["hits"] == int(d.get()[0])
+    poly_show("polygon bench scene (7-gon against pentagon, 1e8 samples)", st)
+    ns = 200_000
+    poses, sds = wl.random_poly_tables(4096, 4096, seed=7)
+    scn = wl.random_poly_scenes(ns, poses, sds, 2.3, seed=8)
+    robot = wl.mc_poly_pair_scene(9, 5)["robot"]
+    d_p, d_s, d_sc = eng.to_device(poses), eng.to_device(sds), eng.to_device(scn)
+    d_h, d_u = eng.zeros(ns, np.uint32), eng.zeros(ns, np.uint32)
+    poly_stats(eng)
+    eng.mc_poly_scenes(robot, d_p, len(poses), d_s, len(sds), d_sc, ns, wl.DEFAULT_BINS, wl.DEFAULT_BIN_ACCURACY, 120_000, 11, 0, d_h, d_u, None)
+    st = poly_stats(eng)
+    assert st["hits"] == int(d_h.get().astype(np.int64).sum()) and st["samples"] == int(d_u.get().astype(np.int64).sum())
+    poly_show("adaptive polygon dataset of the bench (2e5 scenes, max_samples 120 000)", st)
+
+
 def main():
     eng = pkg.Engine(0, lib_path=LIB)
     sc = wl.MC_PAIR_SCENE
@@ -67,6 +111,7 @@ def main():
     st4 = scenes(eng, 4_000_000, 120_000)
     show("config 4 shard (4e6 data points, max_samples 120 000)", st4)
     show("reference-default batch (1e5 data points, max_samples 4 020 000)", scenes(eng, 100_000, 4_020_000))
+    poly_main(eng)
     if "--record" in sys.argv:
         path = os.path.join(ROOT, "profiles", "measured_counts.json")
         cur = json.load(open(path))
