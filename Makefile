@@ -38,10 +38,10 @@ clean:
 	rm -f $(OBJS) $(LIBDIR)/libc2d.so $(BINDIR)/generate_dataset $(BINDIR)/compute_collision_probability $(BINDIR)/ztest
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle drivers tools clean lib-fmad lib-nopretest lib-rehearsal lib-mcstats lib-mcclock
+.PHONY: all lib oracle drivers tools clean lib-fmad lib-nopretest lib-rehearsal lib-mcstats lib-mcclock lib-ab-stamps
 
 # developer tools (not shipped in libc2d.so)
-TOOLS := $(CSRC)/tools/sat_tune $(CSRC)/tools/pose_probe $(CSRC)/tools/clock_probe $(CSRC)/tools/instr_probe $(CSRC)/tools/store_pattern_probe
+TOOLS := $(CSRC)/tools/sat_tune $(CSRC)/tools/pose_probe $(CSRC)/tools/clock_probe $(CSRC)/tools/instr_probe $(CSRC)/tools/store_pattern_probe $(CSRC)/tools/stream_lifetime_probe
 tools: $(TOOLS)
 $(CSRC)/tools/%: $(CSRC)/tools/%.hip $(HDRS)
 	$(HIPCC) -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -Iinclude $< -o $@
@@ -91,3 +91,12 @@ $(CSRC)/c2d_mc_poly_clock.o: $(CSRC)/c2d_mc_poly.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -DC2D_MC_CLOCK -c $< -o $@
 $(LIBDIR)/libc2d_mcclock.so: $(OBJS) $(CSRC)/c2d_mc_clock.o $(CSRC)/c2d_mc_poly_clock.o
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(filter-out $(CSRC)/c2d_mc.o $(CSRC)/c2d_mc_poly.o,$(OBJS)) $(CSRC)/c2d_mc_clock.o $(CSRC)/c2d_mc_poly_clock.o -ldl
+
+# measurement builds (developer tool, not part of `all`): what the completion stamps of the workspace guard cost the counting kernels
+# (csrc/c2d_count.hpp C2D_WS_STAMP_MODE: 0 = none, 2 = with a release fence; the product is 1); compared with the product library in one
+# process by csrc/tools/rect_bench.py (profiles/notes_r05_workspace_guard.md)
+lib-ab-stamps: $(LIBDIR)/libc2d_stamp0.so $(LIBDIR)/libc2d_stamp2.so
+$(LIBDIR)/libc2d_stamp%.so: $(SRCS) $(HDRS)
+	@mkdir -p $(LIBDIR) build/stamp$*
+	for f in $(SRCS); do $(HIPCC) $(HIPFLAGS) -DC2D_WS_STAMP_MODE=$* -c $$f -o build/stamp$*/$$(basename $$f .hip).o || exit 1; done
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ build/stamp$*/*.o -ldl

@@ -95,25 +95,56 @@ def self_launch(n_gpus: int) -> int:
     env.setdefault("OMP_NUM_THREADS", "4")
     # The port was free a moment ago; if something took it before the launcher bound it (its rendezvous then fails with EADDRINUSE
     # before any rank has started), pick another one.  Nothing else is ever retried.
+    import threading
+
+    limit_s = float(os.environ.get("C2D_BENCH_LAUNCH_TIMEOUT_S", "3000"))
+    returncode, out_text = 1, ""
     for attempt in range(3):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
-        sys.stderr.write(proc.stderr)
-        if proc.returncode == 0 or "EADDRINUSE" not in proc.stderr or '"metric"' in proc.stdout:
+        child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+        # The ranks' diagnostics are relayed AS THEY COME (a run that hangs in the rendezvous or in RCCL's start-up must not be
+        # silent), and scanned: the port retry below applies only while no rank has said anything of its own yet.
+        seen = {"addr_in_use": False, "rank_lines": 0, "stdout": []}
+
+        def relay(pipe=child.stderr, seen=seen):
+            for ln in pipe:
+                sys.stderr.write(ln)
+                sys.stderr.flush()
+                if "[bench]" in ln:
+                    seen["rank_lines"] += 1
+                elif "EADDRINUSE" in ln and seen["rank_lines"] == 0:
+                    seen["addr_in_use"] = True
+
+        def collect(pipe=child.stdout, seen=seen):
+            seen["stdout"].append(pipe.read())
+
+        threads = [threading.Thread(target=relay, daemon=True), threading.Thread(target=collect, daemon=True)]
+        for t in threads:
+            t.start()
+        try:
+            returncode = child.wait(timeout=limit_s)
+        except subprocess.TimeoutExpired:
+            child.kill()
+            returncode = child.wait()
+            sys.stderr.write(f"[bench] the {n_gpus} ranks did not finish within {limit_s:.0f} s ($C2D_BENCH_LAUNCH_TIMEOUT_S): killed\n")
+        for t in threads:
+            t.join(timeout=10)
+        out_text = "".join(seen["stdout"])
+        if returncode == 0 or not seen["addr_in_use"] or seen["rank_lines"] or '"metric"' in out_text:
             break
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
     line = None
-    for ln in proc.stdout.splitlines():
+    for ln in out_text.splitlines():
         ln = ln.strip()
         if ln.startswith("{") and '"metric"' in ln:
             line = ln
     if line is not None:
         print(line, flush=True)
-    if proc.returncode != 0:
-        return proc.returncode
+    if returncode != 0:
+        return returncode
     return 0 if line is not None else 1
 
 
@@ -225,6 +256,8 @@ def main() -> None:
     # on one device, so the ranks load the rehearsal build of the library (a sum through files; tests only, `make lib-rehearsal`)
     lib_path = os.path.join(ROOT, "convex-2d-gpu-collision-detection_amd", "lib-rehearsal", "libc2d.so") if args.share_device else None
     eng = pkg.Engine(local_rank, lib_path=lib_path)  # raises if libc2d.so is missing or the device is not gfx950
+    dev_info = eng.info()
+    rccl_version, rccl_library = None, None
     stream = torch.cuda.Stream(device=dev)
     sh = stream.cuda_stream
     counts = measured_counts()
@@ -269,6 +302,12 @@ def main() -> None:
                 dist.destroy_process_group()
                 os._exit(3)  # (a helper thread of the watchdog may still sit inside RCCL)
             reduce_impl = "libc2d c2d_dist_all_reduce_sum_u64 (%s, %d ranks in the communicator)" % (cdist.transport, cdist.world_size)
+            rccl_version, rccl_library = eng.dist_rccl_version()
+        elif args.backend == "nccl":
+            rccl_version, rccl_library = int("%d%02d%02d" % tuple(torch.cuda.nccl.version()[:3])), "torch.distributed (bundled librccl)"
+    # one line per rank on stderr: which card, which RCCL — so that a scaling record can be read without guessing
+    print("[bench] rank %d of %d: device %d (%s, PCI %s), host pid %d, reduce: %s, RCCL %s from %s" % (
+        rank, world, local_rank, dev_info["name"], dev_info["pci_bus_id"] or "?", os.getpid(), reduce_impl, rccl_version, rccl_library), file=sys.stderr, flush=True)
 
     def all_reduce_sum(t):
         """The one collective of each leg: sum of 64-bit counters over ranks, in place (t: int64 device tensor)."""
@@ -995,9 +1034,10 @@ def main() -> None:
                        "pairs_per_gpu": n, "bytes_per_pair": BYTES_PER_PAIR, "collide_rate": round(collide_rate, 5),
                        "parallelism": f"pairs sharded over {world} GPU(s), one process per GPU, no data-path collective, one sum of the hit count per leg",
                        "reduce": reduce_impl,
-                       "ranks_in_reduce": (cdist.world_size if cdist is not None else (dist.get_world_size() if use_dist else 1))},
+                       "ranks_in_reduce": (cdist.world_size if cdist is not None else (dist.get_world_size() if use_dist else 1)),
+                       "rccl_version": rccl_version, "rccl_library": rccl_library, "torch_backend": args.backend if use_dist else None},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "mask_output": mask_leg, "pose_format": pose_leg, "host_resident": host_leg, "mc": mc, "mc_poly": mc_poly, "scenes": scenes_leg, "poly": poly_leg,
-            "device": eng.info()["name"],
+            "device": dev_info["name"], "pci_bus_id": dev_info["pci_bus_id"],
         }
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())

@@ -47,7 +47,7 @@ class _StdDev(C.Structure):
 
 class _DeviceInfo(C.Structure):
     _fields_ = [("name", C.c_char * 128), ("arch", C.c_char * 64), ("device", C.c_int), ("compute_units", C.c_int),
-                ("wavefront_size", C.c_int), ("lds_bytes_per_cu", C.c_int), ("hbm_bytes", C.c_size_t)]
+                ("wavefront_size", C.c_int), ("lds_bytes_per_cu", C.c_int), ("hbm_bytes", C.c_size_t), ("pci_bus_id", C.c_char * 32)]
 
 
 class _PolyBin(C.Structure):
@@ -164,6 +164,7 @@ _SIGNATURES = {
     "c2d_dist_rank": (C.c_int, [C.c_void_p]),
     "c2d_dist_world_size": (C.c_int, [C.c_void_p]),
     "c2d_dist_transport": (C.c_char_p, [C.c_void_p]),
+    "c2d_dist_rccl_version": (C.c_int, [C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
     "c2d_dist_all_reduce_sum_u64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "c2d_dist_broadcast_u64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "c2d_dist_barrier": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -342,7 +343,8 @@ class Engine:
         di = _DeviceInfo()
         self._check(self.lib.c2d_ctx_info(self.h, C.byref(di)), "c2d_ctx_info")
         return {"name": di.name.decode(), "arch": di.arch.decode(), "device": di.device, "compute_units": di.compute_units,
-                "wavefront_size": di.wavefront_size, "lds_bytes_per_cu": di.lds_bytes_per_cu, "hbm_bytes": di.hbm_bytes}
+                "wavefront_size": di.wavefront_size, "lds_bytes_per_cu": di.lds_bytes_per_cu, "hbm_bytes": di.hbm_bytes,
+                "pci_bus_id": di.pci_bus_id.decode()}
 
     def malloc(self, nbytes: int) -> int:
         p = C.c_void_p()
@@ -359,6 +361,15 @@ class Engine:
         self._check(self.lib.c2d_stream_synchronize(self.h, C.c_void_p(stream)), "c2d_stream_synchronize")
 
     # -- multi-GPU ----------------------------------------------------------
+    def dist_rccl_version(self):
+        """(ncclGetVersion code, path of the librccl that c2d_dist loaded) — c2d_dist_rccl_version"""
+        v = C.c_int(0)
+        buf = C.create_string_buffer(1024)
+        st = self.lib.c2d_dist_rccl_version(C.byref(v), buf, 1024)
+        if st != 0:
+            raise C2DError(st, "c2d_dist_rccl_version", self.lib.c2d_status_string(st).decode())
+        return int(v.value), buf.value.decode()
+
     def dist_unique_id(self) -> bytes:
         buf = C.create_string_buffer(DIST_ID_BYTES)
         st = self.lib.c2d_dist_unique_id(buf)

@@ -3,6 +3,28 @@
 // reference mains (compute_collision_probability.cu:212-251, utils.cu:59-72).
 #include "c2d_internal.hpp"
 
+namespace c2d {
+
+__global__ void workspace_stamp_kernel(unsigned long long* stamp, unsigned long long ticket) { atomicMax(stamp, ticket); }
+
+void workspace_stamp_behind(c2d_ctx* ctx, hipStream_t s)
+{
+    if (stream_is_capturing(s)) return;
+    const unsigned long long ticket = ctx->ws_ticket + 1;
+    hipLaunchKernelGGL(workspace_stamp_kernel, dim3(1), dim3(1), 0, s, ctx->d_ws_stamps + kStampOther, ticket);
+    if (hipGetLastError() != hipSuccess) {   // nothing of the call may stay in flight behind an unarmed guard
+        (void)hipStreamSynchronize(s);
+        (void)hipGetLastError();
+        return;
+    }
+    ctx->ws_ticket = ticket;
+    ctx->ws_expect[kStampOther] = ticket;
+    ctx->ws_stream = s;
+    ctx->ws_outstanding = true;
+}
+
+}  // namespace c2d
+
 extern "C" {
 
 int c2d_version(void) { return C2D_VERSION_MAJOR * 1000 + C2D_VERSION_MINOR; }
@@ -46,15 +68,13 @@ int c2d_ctx_create(int device, c2d_ctx** out)
     if (std::strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) { delete ctx; return C2D_ERR_NO_DEVICE; }
     c2d::DeviceGuard g(device);
     if (!g.ok) { delete ctx; return C2D_ERR_NO_DEVICE; }
-    if (hipMalloc(&ctx->d_counters, 64) != hipSuccess || hipMalloc(&ctx->d_count_words, C2D_COUNT_WORDS_BYTES) != hipSuccess ||
-        hipMemset(ctx->d_count_words, 0, C2D_COUNT_WORDS_BYTES) != hipSuccess || hipMalloc(&ctx->d_count_words2, C2D_COUNT_WORDS2_BYTES) != hipSuccess ||
-        hipMemset(ctx->d_count_words2, 0, C2D_COUNT_WORDS2_BYTES) != hipSuccess || hipMalloc(&ctx->d_bins, 32 * sizeof(float)) != hipSuccess ||
+    if (hipMalloc(&ctx->d_counters, 64) != hipSuccess || hipMalloc(&ctx->d_count_words, c2d::kWorkspaceBytes) != hipSuccess ||
+        hipMemset(ctx->d_count_words, 0, c2d::kWorkspaceBytes) != hipSuccess || hipMalloc(&ctx->d_bins, 32 * sizeof(float)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pinned), 64, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&ctx->h_async_err), 64, hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->d_async_err), ctx->h_async_err, 0) != hipSuccess) {
         if (ctx->d_counters) (void)hipFree(ctx->d_counters);
         if (ctx->d_count_words) (void)hipFree(ctx->d_count_words);
-        if (ctx->d_count_words2) (void)hipFree(ctx->d_count_words2);
         if (ctx->d_bins) (void)hipFree(ctx->d_bins);
         if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
         if (ctx->h_async_err) (void)hipHostFree(ctx->h_async_err);
@@ -62,6 +82,8 @@ int c2d_ctx_create(int device, c2d_ctx** out)
         return C2D_ERR_NOMEM;
     }
     *ctx->h_async_err = 0;
+    ctx->d_count_words2 = ctx->d_count_words + c2d::kCountWordsBytes / 8;
+    ctx->d_ws_stamps = ctx->d_count_words + c2d::kWorkspaceStampsOffset / 8;
     *out = ctx;
     return C2D_OK;
 }
@@ -74,7 +96,8 @@ int c2d_ctx_destroy(c2d_ctx* ctx)
         if (p) (void)hipFree(p);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_count_words) (void)hipFree(ctx->d_count_words);
-    if (ctx->d_count_words2) (void)hipFree(ctx->d_count_words2);
+    if (ctx->ws_probe_stream) (void)hipStreamDestroy(ctx->ws_probe_stream);
+    if (ctx->h_ws_block) (void)hipHostFree(ctx->h_ws_block);
     if (ctx->d_bins) (void)hipFree(ctx->d_bins);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     c2d_host_pipe_free(ctx->host_pipe);
@@ -88,13 +111,18 @@ int c2d_ctx_info(const c2d_ctx* ctx, c2d_device_info* out)
 {
     if (!ctx || !out) return C2D_ERR_INVALID_ARG;
     std::memset(out, 0, sizeof *out);
-    std::snprintf(out->name, sizeof out->name, "%s", ctx->prop.name);
+    // (some boxes of the pool report an empty marketing name: the architecture then stands in for it)
+    std::snprintf(out->name, sizeof out->name, "%s", ctx->prop.name[0] ? ctx->prop.name : ctx->prop.gcnArchName);
     std::snprintf(out->arch, sizeof out->arch, "%s", ctx->prop.gcnArchName);
     out->device = ctx->device;
     out->compute_units = ctx->prop.multiProcessorCount;
     out->wavefront_size = ctx->prop.warpSize;
     out->lds_bytes_per_cu = (int)ctx->prop.maxSharedMemoryPerMultiProcessor;
     out->hbm_bytes = ctx->prop.totalGlobalMem;
+    if (hipDeviceGetPCIBusId(out->pci_bus_id, (int)sizeof out->pci_bus_id, ctx->device) != hipSuccess) {
+        (void)hipGetLastError();
+        out->pci_bus_id[0] = 0;
+    }
     return C2D_OK;
 }
 
@@ -182,11 +210,7 @@ int c2d_stream_destroy(c2d_ctx* ctx, c2d_stream stream)
     if (!ctx) return C2D_ERR_INVALID_ARG;
     if (!stream) return C2D_OK;
     c2d::DeviceGuard g(ctx->device);
-    if (ctx->ws_busy && ctx->ws_stream == (hipStream_t)stream) {  // the workspace guard must not query a dead handle
-        C2D_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
-        ctx->ws_busy = false;
-    }
-    C2D_HIP(ctx, hipStreamDestroy((hipStream_t)stream));
+    C2D_HIP(ctx, hipStreamDestroy((hipStream_t)stream));  // (the workspace guard never touches a stream handle: c2d_internal.hpp)
     return C2D_OK;
 }
 
@@ -195,6 +219,7 @@ int c2d_stream_synchronize(c2d_ctx* ctx, c2d_stream stream)
     if (!ctx) return C2D_ERR_INVALID_ARG;
     c2d::DeviceGuard g(ctx->device);
     C2D_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    c2d::workspace_stream_drained(ctx, (hipStream_t)stream);
     return c2d_ctx_check_async(ctx);
 }
 

@@ -19,11 +19,54 @@ namespace c2d {
 // the sum to the caller's counter — at most 256 adds on that word per launch.
 // Measured against per-block partials + a finishing kernel: 105.4 vs 107.9 us.
 constexpr uint32_t kCountWords = 256;  // x 128 B = 32 KiB of ctx workspace
+constexpr uint32_t kCountWords1 = 2048;   // two-level form below: x 64 B
+constexpr uint32_t kCountWords2 = 32;     // x 128 B, behind the first level
+constexpr size_t kCountWordsBytes = (size_t)kCountWords * 128;
+constexpr size_t kCountWords2Bytes = (size_t)kCountWords1 * 64 + (size_t)kCountWords2 * 128;
+
+// Completion stamps of the workspace (the guard in c2d_internal.hpp): ONE block holds the single-level words, the two-level
+// words and, behind them, one 64-bit stamp per word that can complete a launch — 256 for the single-level form, 32 for the
+// second level of the two-level form, 1 for the calls that stamp with a kernel of their own (the adaptive Monte-Carlo
+// schedule).  A launch carries a ticket; the wave that completes a word raises that word's stamp to the ticket, so the host
+// can tell "everything this ctx launched on its workspace has retired" from the stamps alone — without asking the runtime
+// about a stream handle whose lifetime belongs to the caller.  Ticket 0 = no stamping (graph capture).
+constexpr uint32_t kStampOther = kCountWords + kCountWords2;   // index of the extra stamp
+constexpr uint32_t kStampSlots = kStampOther + 1;
+constexpr size_t kWorkspaceStampsOffset = kCountWordsBytes + kCountWords2Bytes;           // bytes from the start of the block
+constexpr size_t kWorkspaceBytes = kWorkspaceStampsOffset + (size_t)kStampSlots * 8;
+
+struct CountWs {
+    unsigned long long* words;   // the single-level words (block + 0) or the two-level words (block + kCountWordsBytes)
+    unsigned long long ticket;
+};
+
+// The stamp is ONE relaxed, non-returning atomic behind the word's clearing — no fence between the two.  A release fence there
+// costs 1 % of the 104-us headline kernel (256 completing waves wait for their writes and write the L2 back at the kernel's
+// tail; measured A/B in one process, profiles/notes_r05_workspace_guard.md), and it is not needed: the guard accepts a word only
+// when it reads the stamp raised AND the word itself back at zero.  A raised stamp means every arrival at the word has been
+// performed (the completing wave held the full count), after which the word stays non-zero until the clearing lands — so
+// "raised and zero" is the final state whatever order the two atomics reach memory in.
+// (C2D_WS_STAMP_MODE is a measurement switch of `make lib-ab-stamps`: 0 = no stamp at all — round 4's kernels, and a guard that
+// refuses for ever —, 2 = with the release fence; the product is 1)
+#ifndef C2D_WS_STAMP_MODE
+#define C2D_WS_STAMP_MODE 1
+#endif
+C2D_DEV void stamp_raise(unsigned long long* stamp, unsigned long long ticket)
+{
+#if C2D_WS_STAMP_MODE > 0
+    if (ticket) {
+#if C2D_WS_STAMP_MODE > 1
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
+        atomicMax(stamp, ticket);
+    }
+#endif
+}
 
 // `v` is the wave's total (wave-uniform); every wave of the grid must call this exactly once.
-C2D_DEV void wave_count_arrive_total(uint32_t v, unsigned long long* __restrict__ d_count,
-                                     unsigned long long* __restrict__ words)
+C2D_DEV void wave_count_arrive_total(uint32_t v, unsigned long long* __restrict__ d_count, CountWs ws)
 {
+    unsigned long long* __restrict__ words = ws.words;
     if ((threadIdx.x & 63) == 0) {
         const uint32_t waves_per_block = blockDim.x >> 6;
         const uint32_t wave_id = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
@@ -36,6 +79,7 @@ C2D_DEV void wave_count_arrive_total(uint32_t v, unsigned long long* __restrict_
             const unsigned long long total = (old & ((1ull << 40) - 1)) + v;
             atomicExch(w, 0ull);
             if (total) atomicAdd(d_count, total);
+            stamp_raise(words + kWorkspaceStampsOffset / 8 + slot, ws.ticket);
         }
     }
 }
@@ -46,12 +90,9 @@ C2D_DEV void wave_count_arrive_total(uint32_t v, unsigned long long* __restrict_
 // Here a wave arrives at one of 2048 first-level words (76 arrivals each at that size); the wave that completes a
 // first-level word carries its sum to one of 32 second-level words, and the wave that completes one of those adds to the
 // caller's counter: at most 32 adds on that word, every chain short, all words self-clearing as above.
-constexpr uint32_t kCountWords1 = 2048;   // x 64 B
-constexpr uint32_t kCountWords2 = 32;     // x 128 B, behind the first level in the same workspace block
-constexpr size_t kCountWords2Bytes = (size_t)kCountWords1 * 64 + (size_t)kCountWords2 * 128;
-
-C2D_DEV void wave_count_arrive_total2(uint32_t v, unsigned long long* __restrict__ d_count, unsigned long long* __restrict__ words2)
+C2D_DEV void wave_count_arrive_total2(uint32_t v, unsigned long long* __restrict__ d_count, CountWs ws)
 {
+    unsigned long long* __restrict__ words2 = ws.words;
     if ((threadIdx.x & 63) == 0) {
         const uint32_t waves_per_block = blockDim.x >> 6;
         const uint32_t wave_id = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
@@ -72,19 +113,19 @@ C2D_DEV void wave_count_arrive_total2(uint32_t v, unsigned long long* __restrict
                 const unsigned long long total2 = (old2 & ((1ull << 40) - 1)) + total1;
                 atomicExch(w2, 0ull);
                 if (total2) atomicAdd(d_count, total2);
+                stamp_raise(words2 + (kWorkspaceStampsOffset - kCountWordsBytes) / 8 + kCountWords + slot2, ws.ticket);
             }
         }
     }
 }
 
 // per-lane partial counts
-C2D_DEV void wave_count_arrive(uint32_t lane_count, unsigned long long* __restrict__ d_count,
-                               unsigned long long* __restrict__ words)
+C2D_DEV void wave_count_arrive(uint32_t lane_count, unsigned long long* __restrict__ d_count, CountWs ws)
 {
     uint32_t v = lane_count;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    wave_count_arrive_total((uint32_t)__builtin_amdgcn_readfirstlane((int)v), d_count, words);
+    wave_count_arrive_total((uint32_t)__builtin_amdgcn_readfirstlane((int)v), d_count, ws);
 }
 
 }  // namespace c2d

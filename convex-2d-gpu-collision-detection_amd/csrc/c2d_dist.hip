@@ -30,14 +30,12 @@
 #include <unistd.h>
 
 #include <chrono>
-#include <condition_variable>
 #include <cstdlib>
-#include <memory>
-#include <mutex>
 #include <thread>
 #include <vector>
 
 #include "c2d_internal.hpp"
+#include "c2d_watchdog.hpp"
 
 static_assert(sizeof(ncclUniqueId) == C2D_DIST_ID_BYTES, "C2D_DIST_ID_BYTES must match ncclUniqueId");
 
@@ -128,32 +126,8 @@ bool read_file_when_complete(const std::string& path, void* data, size_t bytes, 
     }
 }
 
-// Runs `fn` on a helper thread and waits for it for at most timeout_s seconds.  false: the deadline passed; the thread
-// is detached and stays wherever it blocks (inside RCCL), so everything it touches must be kept alive by `fn` itself.
-template <class F>
-bool run_with_deadline(F fn, double timeout_s)
-{
-    struct Shared { std::mutex m; std::condition_variable cv; bool done = false; };
-    auto sh = std::make_shared<Shared>();
-    std::thread t([sh, fn]() mutable {
-        fn();
-        { std::lock_guard<std::mutex> lk(sh->m); sh->done = true; }
-        sh->cv.notify_all();
-    });
-    std::unique_lock<std::mutex> lk(sh->m);
-    const bool ok = sh->cv.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return sh->done; });
-    lk.unlock();
-    if (ok) t.join();
-    else t.detach();
-    return ok;
-}
-
-double default_timeout_s()
-{
-    const char* t = std::getenv("C2D_DIST_TIMEOUT_S");
-    const double v = t ? std::atof(t) : 0.0;
-    return v > 0.0 ? v : 300.0;
-}
+using c2d::watchdog::default_timeout_s;   // the deadline mechanics live in c2d_watchdog.hpp (thread-sanitised on the CPU)
+using c2d::watchdog::run_job;
 
 }  // namespace
 
@@ -162,7 +136,6 @@ struct c2d_dist {
     int rank = 0, world = 1;
     ncclComm_t comm = nullptr;
     double timeout_s = 300.0;
-    std::string error;     // set by the helper thread of the watchdog (ncclCommInitRank only)
     bool timed_out = false; // a watched call ran out of time: a helper thread is still inside RCCL / HIP with this communicator,
                             // which must neither be used nor destroyed any more
 #ifdef C2D_DIST_REHEARSAL
@@ -251,22 +224,26 @@ static int dist_init_impl(c2d_ctx* ctx, int rank, int world_size, const void* id
     ncclUniqueId uid;
     std::memcpy(&uid, id, sizeof uid);
     const int device = ctx->device;
-    // ncclCommInitRank returns once every rank has joined; a peer that never arrives would block it for ever
-    const bool in_time = run_with_deadline([d, uid, world_size, rank, device]() {
-        if (hipSetDevice(device) != hipSuccess) { d->error = "hipSetDevice failed on the communicator thread"; return; }
-        const ncclResult_t st = rccl().CommInitRank(&d->comm, world_size, uid, rank);
-        if (st != ncclSuccess) d->error = std::string("ncclCommInitRank failed: ") + rccl().GetErrorString(st);
-    }, timeout_s);
-    if (!in_time) {  // `d` stays allocated: the abandoned thread still points at it
+    // ncclCommInitRank returns once every rank has joined; a peer that never arrives would block it for ever.  The helper writes
+    // the communicator into ITS job block, not into `d`: after a time-out nothing of this call is shared with it any more.
+    struct InitJob : c2d::watchdog::Job { ncclComm_t comm = nullptr; };
+    InitJob res;
+    const bool in_time = run_job<InitJob>([uid, world_size, rank, device](InitJob& job) {
+        if (hipSetDevice(device) != hipSuccess) { job.st = C2D_ERR_HIP; job.error = "hipSetDevice failed on the communicator thread"; return; }
+        const ncclResult_t st = rccl().CommInitRank(&job.comm, world_size, uid, rank);
+        if (st != ncclSuccess) { job.st = C2D_ERR_DIST; job.error = std::string("ncclCommInitRank failed: ") + rccl().GetErrorString(st); }
+    }, timeout_s, &res);
+    if (!in_time) {
+        delete d;
         char msg[160];
         std::snprintf(msg, sizeof msg, "rank %d: ncclCommInitRank did not complete within %.0f s (are all %d ranks running?)", rank, timeout_s, world_size);
         return fail_dist(ctx, msg);
     }
-    if (!d->error.empty()) {
-        const std::string e = d->error;
+    if (res.st != C2D_OK) {
         delete d;
-        return fail_dist(ctx, e);
+        return fail_dist(ctx, res.error, res.st);
     }
+    d->comm = res.comm;
     *out = d;
     return C2D_OK;
 #endif
@@ -327,6 +304,25 @@ const char* c2d_dist_transport(const c2d_dist* d)
 #endif
 }
 
+int c2d_dist_rccl_version(int* version, char* path_out, size_t path_bytes)
+{
+    if (!version) return C2D_ERR_INVALID_ARG;
+    *version = 0;
+    if (path_out && path_bytes) path_out[0] = 0;
+#ifdef C2D_DIST_REHEARSAL
+    if (path_out && path_bytes) std::snprintf(path_out, path_bytes, "file (rehearsal)");
+    return C2D_OK;
+#else
+    Rccl& R = rccl();
+    if (!R.handle) return C2D_ERR_DIST;
+    if (R.GetVersion(version) != ncclSuccess) return C2D_ERR_DIST;
+    Dl_info info;
+    if (path_out && path_bytes && dladdr(reinterpret_cast<void*>(R.GetVersion), &info) && info.dli_fname)
+        std::snprintf(path_out, path_bytes, "%s", info.dli_fname);
+    return C2D_OK;
+#endif
+}
+
 int c2d_dist_all_reduce_sum_u64(c2d_dist* d, unsigned long long* d_buf, size_t count, c2d_stream stream)
 {
     if (!d || (!d_buf && count)) return C2D_ERR_INVALID_ARG;
@@ -372,41 +368,40 @@ int c2d_dist_barrier(c2d_dist* d, c2d_stream stream)
 {
     if (!d) return C2D_ERR_INVALID_ARG;
     if (d->timed_out) return fail_dist(d->ctx, "this communicator was abandoned after a time-out");
-    struct Job { int st = C2D_OK; std::string error; };
-    auto job = std::make_shared<Job>();
     const int device = d->ctx->device;
+    // The helper keeps `d` (left alone by c2d_dist_destroy after a time-out) and the communicator inside it, nothing of the ctx.
+    c2d::watchdog::Job res;
 #ifdef C2D_DIST_REHEARSAL
     c2d_ctx* ctx = d->ctx;
+    const double limit = d->timeout_s + 10.0;  // (the file transport has this limit built in: let it report its own time-out)
+#else
+    const double limit = d->timeout_s;
 #endif
-    const bool in_time = run_with_deadline([=]() {
-        if (hipSetDevice(device) != hipSuccess) { job->st = C2D_ERR_HIP; job->error = "hipSetDevice failed on the barrier thread"; return; }
+    const bool in_time = run_job<c2d::watchdog::Job>([=](c2d::watchdog::Job& job) {
+        if (hipSetDevice(device) != hipSuccess) { job.st = C2D_ERR_HIP; job.error = "hipSetDevice failed on the barrier thread"; return; }
         unsigned long long* w = nullptr;
-        if (hipMalloc(&w, sizeof *w) != hipSuccess) { job->st = C2D_ERR_NOMEM; job->error = "barrier word allocation failed"; return; }
-        if (hipMemsetAsync(w, 0, sizeof *w, (hipStream_t)stream) != hipSuccess) { job->st = C2D_ERR_HIP; job->error = "hipMemsetAsync failed in the barrier"; }
-        if (job->st == C2D_OK) {
+        if (hipMalloc(&w, sizeof *w) != hipSuccess) { job.st = C2D_ERR_NOMEM; job.error = "barrier word allocation failed"; return; }
+        if (hipMemsetAsync(w, 0, sizeof *w, (hipStream_t)stream) != hipSuccess) { job.st = C2D_ERR_HIP; job.error = "hipMemsetAsync failed in the barrier"; }
+        if (job.st == C2D_OK) {
 #ifdef C2D_DIST_REHEARSAL
-            job->st = c2d_dist_all_reduce_sum_u64(d, w, 1, stream);  // (the file transport runs on the caller's side of the deadline anyway)
-            if (job->st != C2D_OK) job->error = ctx->last_error;
+            job.st = c2d_dist_all_reduce_sum_u64(d, w, 1, stream);  // (the file transport runs on the caller's side of the deadline anyway)
+            if (job.st != C2D_OK) job.error = ctx->last_error;
 #else
             const ncclResult_t st = rccl().AllReduce(w, w, 1, ncclUint64, ncclSum, d->comm, (hipStream_t)stream);
-            if (st != ncclSuccess) { job->st = C2D_ERR_DIST; job->error = std::string("ncclAllReduce failed: ") + rccl().GetErrorString(st); }
+            if (st != ncclSuccess) { job.st = C2D_ERR_DIST; job.error = std::string("ncclAllReduce failed: ") + rccl().GetErrorString(st); }
 #endif
         }
-        if (job->st == C2D_OK && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) { job->st = C2D_ERR_HIP; job->error = "hipStreamSynchronize failed in the barrier"; }
+        if (job.st == C2D_OK && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) { job.st = C2D_ERR_HIP; job.error = "hipStreamSynchronize failed in the barrier"; }
         (void)hipFree(w);
-#ifdef C2D_DIST_REHEARSAL
-    }, d->timeout_s + 10.0);  // (the file transport has this limit built in: let it report its own time-out)
-#else
-    }, d->timeout_s);
-#endif
+    }, limit, &res);
     if (!in_time) {
         d->timed_out = true;
         char msg[160];
         std::snprintf(msg, sizeof msg, "rank %d: barrier did not complete within %.0f s (a peer is missing or stuck)", d->rank, d->timeout_s);
         return fail_dist(d->ctx, msg);
     }
-    if (job->st != C2D_OK && !job->error.empty()) d->ctx->last_error = job->error;
-    return job->st;
+    if (res.st != C2D_OK && !res.error.empty()) d->ctx->last_error = res.error;
+    return res.st;
 }
 
 // hipStreamSynchronize under the same watchdog, for the collectives a caller has queued itself (c2d_dist_all_reduce_sum_u64 /
@@ -416,19 +411,18 @@ int c2d_dist_stream_synchronize(c2d_dist* d, c2d_stream stream)
 {
     if (!d) return C2D_ERR_INVALID_ARG;
     if (d->timed_out) return fail_dist(d->ctx, "this communicator was abandoned after a time-out");
-    struct Job { int st = C2D_OK; };
-    auto job = std::make_shared<Job>();
     const int device = d->ctx->device;
-    const bool in_time = run_with_deadline([=]() {
-        if (hipSetDevice(device) != hipSuccess || hipStreamSynchronize((hipStream_t)stream) != hipSuccess) job->st = C2D_ERR_HIP;
-    }, d->timeout_s);
+    c2d::watchdog::Job res;
+    const bool in_time = run_job<c2d::watchdog::Job>([=](c2d::watchdog::Job& job) {
+        if (hipSetDevice(device) != hipSuccess || hipStreamSynchronize((hipStream_t)stream) != hipSuccess) job.st = C2D_ERR_HIP;
+    }, d->timeout_s, &res);
     if (!in_time) {
         d->timed_out = true;
         char msg[160];
         std::snprintf(msg, sizeof msg, "rank %d: a collective did not complete within %.0f s (a peer is missing or stuck)", d->rank, d->timeout_s);
         return fail_dist(d->ctx, msg);
     }
-    if (job->st != C2D_OK) return fail_dist(d->ctx, "hipStreamSynchronize failed behind a collective", C2D_ERR_HIP);
+    if (res.st != C2D_OK) return fail_dist(d->ctx, "hipStreamSynchronize failed behind a collective", C2D_ERR_HIP);
     return c2d_ctx_check_async(d->ctx);
 }
 

@@ -100,7 +100,7 @@ int run_host_batch(c2d_ctx* ctx, const float* const* h_planes, size_t n, uint8_t
     }
     e = hipStreamSynchronize(s);  // (also after an error: nothing of this call stays in flight)
     if (e != hipSuccess && st == C2D_OK) st = fail_hip(ctx, e, "hipStreamSynchronize", __FILE__, __LINE__);
-    ctx->ws_busy = false;         // the count workspace was used on this call's own stream, which has drained
+    if (e == hipSuccess) workspace_stream_drained(ctx, s);   // (only tickets issued on this call's own stream count as retired)
     return st;
 }
 

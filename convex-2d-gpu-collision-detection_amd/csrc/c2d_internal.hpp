@@ -8,6 +8,7 @@
 #include <string>
 
 #include "../../include/c2d.h"
+#include "c2d_count.hpp"
 
 struct c2d_host_pipe;                              // stream and buffers of the host-resident entry points (c2d_host.hip)
 void c2d_host_pipe_free(c2d_host_pipe* p);
@@ -19,8 +20,11 @@ struct c2d_ctx {
     uint32_t* d_list[2] = {nullptr, nullptr};  // active-scene index lists
     size_t list_capacity = 0;
     uint32_t* d_counters = nullptr;            // [0] next-active count
-    unsigned long long* d_count_words = nullptr;  // 256 x 128 B arrival/sum words of the SAT count (self-clearing)
-    unsigned long long* d_count_words2 = nullptr; // two-level form for the polygon kernels (c2d_count.hpp), self-clearing
+    // ONE block (c2d_count.hpp): 256 x 128 B arrival/sum words of the SAT count | the two-level form for the polygon kernels |
+    // the completion stamps of the workspace guard.  The words are self-clearing, the stamps only ever rise.
+    unsigned long long* d_count_words = nullptr;
+    unsigned long long* d_count_words2 = nullptr; // = d_count_words + kCountWordsBytes / 8
+    unsigned long long* d_ws_stamps = nullptr;    // = d_count_words + kWorkspaceStampsOffset / 8
     float* d_bins = nullptr;                   // accuracy_bins | bin_accuracy (<= 32 floats)
     c2d_host_pipe* host_pipe = nullptr;        // made at the first c2d_sat_rect_pairs_*_host call, kept
     void* d_scratch = nullptr;                 // grown on demand, kept: the binning pass's histograms and tables (c2d_poly_bins_from_padded)
@@ -31,17 +35,20 @@ struct c2d_ctx {
     // c2d_ctx_check_async read and clear it, so asynchronous entry points need no validation pass.
     uint32_t* h_async_err = nullptr;
     uint32_t* d_async_err = nullptr;           // device address of the same word
-    // Guard of the shared workspace (count words, adaptive state, survivor lists): the stream of the last call that
-    // used it; a workspace call on another stream while that stream still has work queued is refused.
+    // Guard of the shared workspace (count words, adaptive state, survivor lists, scratch): see workspace_acquire below.
+    // ws_stream is only ever COMPARED with the stream of the next call, never handed to the runtime: the caller may have
+    // destroyed it.
     hipStream_t ws_stream = nullptr;
-    bool ws_busy = false;
+    bool ws_outstanding = false;                    // tickets were issued (on ws_stream) that no check has seen retired yet
+    unsigned long long ws_ticket = 0;               // the last ticket handed out
+    unsigned long long ws_expect[c2d::kStampSlots] = {};  // per stamp: the ticket it must have reached
+    hipStream_t ws_probe_stream = nullptr;          // the guard's own stream and page-locked copy of the workspace block (words and
+    unsigned long long* h_ws_block = nullptr;       // stamps), made at the first check that needs them
     mutable std::string last_error;
 };
 
 #define C2D_ASYNC_ERR_POLY_K 1u   /* polygon vertex count outside 1..C2D_POLY_KMAX */
 
-#define C2D_COUNT_WORDS_BYTES (256 * 128)
-#define C2D_COUNT_WORDS2_BYTES (2048 * 64 + 32 * 128)
 
 namespace c2d {
 
@@ -90,27 +97,109 @@ struct DeviceGuard {
 
 constexpr int kMaxGrid = 1 << 24;  // blocks per launch; kernels grid-stride beyond it
 
-// Guard of the ctx workspace.  Calls on ONE stream are ordered by the stream; a workspace call on another stream is only
-// accepted once everything queued on the previous workspace stream has completed (hipStreamQuery: a host-side check that
-// puts nothing into either stream — an event per call costs a few microseconds of gap between back-to-back 100-us
-// kernels).  Otherwise it returns C2D_ERR_UNSUPPORTED instead of silently corrupting both calls.
+// Guard of the ctx workspace (count words, adaptive state, survivor lists, scratch).  Calls on ONE stream are ordered by
+// the stream; a workspace call on ANOTHER stream is accepted only once everything the ctx launched on its workspace has
+// retired, and is refused with C2D_ERR_UNSUPPORTED otherwise instead of silently corrupting both calls.
+//
+// "Has retired" is read from completion stamps the kernels raise themselves (c2d_count.hpp): every launch that uses the
+// workspace carries a ticket, the wave that completes one of the launch's count words raises that word's stamp to the
+// ticket (calls without counting kernels stamp with a one-thread kernel behind their last launch), and the host remembers
+// per stamp the ticket it must reach.  The check is one read of the workspace block (167 KB: the words and their stamps) on a
+// stream the ctx owns, made only when the stream changes while tickets are outstanding: a word counts as retired when its
+// stamp has reached its ticket AND the word itself reads zero again (c2d_count.hpp: that pair is the final state whatever order
+// the kernel's two atomics land in, so the kernels need no fence).  The hot path pays one 64-bit kernel argument and one
+// non-returning atomic per completed word.  Round 4 asked the runtime instead (hipStreamQuery on the previous call's stream) — a handle whose
+// lifetime belongs to the caller; profiles/notes_r05_workspace_guard.md has what that cost.
+//
+// Graph capture: a call on a capturing stream takes no ticket and makes no check — nothing executes during capture, and
+// the order of a graph's replays against other work on the ctx is the caller's, as include/c2d.h states.
+inline bool stream_is_capturing(hipStream_t s)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return st != hipStreamCaptureStatusNone;
+}
+
 inline int workspace_acquire(c2d_ctx* ctx, hipStream_t s, bool uses)
 {
-    if (!uses || !ctx->ws_busy || ctx->ws_stream == s) return C2D_OK;
-    if (hipStreamQuery(ctx->ws_stream) == hipErrorNotReady) {
+    if (!uses || !ctx->ws_outstanding || ctx->ws_stream == s) return C2D_OK;
+    if (stream_is_capturing(s)) return C2D_OK;
+    if (!ctx->ws_probe_stream) {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->ws_probe_stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&ctx->h_ws_block), kWorkspaceBytes, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            if (ctx->ws_probe_stream) { (void)hipStreamDestroy(ctx->ws_probe_stream); ctx->ws_probe_stream = nullptr; }
+            return fail_hip(ctx, e, "workspace guard set-up", __FILE__, __LINE__);
+        }
+    }
+    hipError_t e = hipMemcpyAsync(ctx->h_ws_block, ctx->d_count_words, kWorkspaceBytes, hipMemcpyDeviceToHost, ctx->ws_probe_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->ws_probe_stream);
+    if (e != hipSuccess) return fail_hip(ctx, e, "workspace guard read", __FILE__, __LINE__);
+    const unsigned long long* words = ctx->h_ws_block;                                  // 256 words, 128 bytes apart
+    const unsigned long long* words1 = ctx->h_ws_block + kCountWordsBytes / 8;          // 2048 first-level words, 64 bytes apart
+    const unsigned long long* words2 = words1 + (size_t)kCountWords1 * 8;               // 32 second-level words, 128 bytes apart
+    const unsigned long long* stamps = ctx->h_ws_block + kWorkspaceStampsOffset / 8;
+    bool busy = false;
+    for (uint32_t i = 0; i < kStampSlots && !busy; i++) busy = stamps[i] < ctx->ws_expect[i];
+    for (uint32_t i = 0; i < kCountWords && !busy; i++) busy = words[(size_t)i * 16] != 0;
+    for (uint32_t i = 0; i < kCountWords1 && !busy; i++) busy = words1[(size_t)i * 8] != 0;
+    for (uint32_t i = 0; i < kCountWords2 && !busy; i++) busy = words2[(size_t)i * 16] != 0;
+    if (busy) {
         ctx->last_error = "this c2d_ctx still has a call in flight on another stream (one workspace per ctx: use one ctx per stream)";
         return C2D_ERR_UNSUPPORTED;
     }
-    (void)hipGetLastError();  // a stream the caller has destroyed meanwhile reads as an invalid handle: nothing in flight
-    ctx->ws_busy = false;
+    ctx->ws_outstanding = false;
     return C2D_OK;
 }
 
-inline void workspace_release(c2d_ctx* ctx, hipStream_t s, bool uses)
+// the ticket of one launch whose waves count through the single-level words / the two-level words; call it right before the
+// launch on stream `s` with the launch's number of waves
+inline CountWs workspace_count_ticket(c2d_ctx* ctx, hipStream_t s, size_t n_waves, bool counted)
 {
-    if (!uses) return;
+    CountWs ws{ctx->d_count_words, 0};
+    if (!counted || stream_is_capturing(s)) return ws;
+    ws.ticket = ++ctx->ws_ticket;
+    const size_t used = n_waves < kCountWords ? n_waves : kCountWords;
+    for (size_t i = 0; i < used; i++) ctx->ws_expect[i] = ws.ticket;
     ctx->ws_stream = s;
-    ctx->ws_busy = true;
+    ctx->ws_outstanding = true;
+    return ws;
+}
+
+inline CountWs workspace_count_ticket2(c2d_ctx* ctx, hipStream_t s, size_t n_waves, bool counted)
+{
+    CountWs ws{ctx->d_count_words2, 0};
+    if (!counted || stream_is_capturing(s)) return ws;
+    ws.ticket = ++ctx->ws_ticket;
+    size_t used = n_waves < kCountWords1 ? n_waves : kCountWords1;
+    used = used < kCountWords2 ? used : kCountWords2;
+    for (size_t i = 0; i < used; i++) ctx->ws_expect[kCountWords + i] = ws.ticket;
+    ctx->ws_stream = s;
+    ctx->ws_outstanding = true;
+    return ws;
+}
+
+// For calls whose kernels do not count (the adaptive schedule): a one-thread kernel behind everything the call has queued on
+// `s` raises the extra stamp.  If even that cannot be launched the stream is drained instead, so that nothing of the call
+// stays in flight unguarded.  (c2d_api.hip)
+void workspace_stamp_behind(c2d_ctx* ctx, hipStream_t s);
+
+// Arms at the call's first enqueue and stamps on EVERY way out of the scope, error returns included.
+struct WorkspaceUse {
+    c2d_ctx* ctx;
+    hipStream_t s;
+    bool armed = false;
+    WorkspaceUse(c2d_ctx* c, hipStream_t st) : ctx(c), s(st) {}
+    WorkspaceUse(const WorkspaceUse&) = delete;
+    WorkspaceUse& operator=(const WorkspaceUse&) = delete;
+    void arm() { armed = true; }
+    ~WorkspaceUse() { if (armed) workspace_stamp_behind(ctx, s); }
+};
+
+// `s` has been synchronised by the caller: if it is the stream the outstanding tickets were issued on, they have retired.
+inline void workspace_stream_drained(c2d_ctx* ctx, hipStream_t s)
+{
+    if (ctx->ws_outstanding && ctx->ws_stream == s) ctx->ws_outstanding = false;
 }
 
 inline int grid_for(size_t work_items, int block, int max_blocks)

@@ -580,6 +580,10 @@ int run_adaptive(c2d_ctx* ctx, const c2d_mc_scenes_args* a, c2d_stream stream, A
     AdaptiveState* d_state = reinterpret_cast<AdaptiveState*>(ctx->d_counters);
     static_assert(sizeof(AdaptiveState) <= 64, "AdaptiveState must fit the ctx counter block");
 
+    // from here on the ctx state block and lists are in use on `s`: every way out of this function, the error returns
+    // included, leaves the guard's stamp behind what was queued (c2d_internal.hpp)
+    WorkspaceUse use(ctx, s);
+    use.arm();
     launch_mc_scenes_init(s, d_state, (uint32_t)a->n_scenes);
     C2D_HIP(ctx, hipMemsetAsync(a->d_hits, 0, a->n_scenes * sizeof(uint32_t), s));
     // Burst: the leading steps that all use the small batch, when that batch is one work item per scene anyway
@@ -635,7 +639,6 @@ int run_adaptive(c2d_ctx* ctx, const c2d_mc_scenes_args* a, c2d_stream stream, A
         }
     }
     C2D_LAUNCH_CHECK(ctx);
-    workspace_release(ctx, s, true);
     if (host_out) {  // host outputs requested: one read-back at the end
         C2D_HIP(ctx, hipMemcpyAsync(h_state, d_state, sizeof(AdaptiveState), hipMemcpyDeviceToHost, s));
         C2D_HIP(ctx, hipStreamSynchronize(s));

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void sat_poly_kernel(const float* __
                                                                  const uint8_t* __restrict__ kcnt, size_t n, int rows_arg,
                                                                  uint8_t* __restrict__ out,
                                                                  unsigned long long* __restrict__ d_count,
-                                                                 unsigned long long* __restrict__ words,
+                                                                 CountWs words,
                                                                  uint32_t* __restrict__ async_err)
 {
     const int rows = FULL ? KM : rows_arg;  // FULL: the layout has exactly KM rows (a compile-time constant)
@@ -267,7 +267,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(64) void sat_poly4_kernel(const float* __restrict__ vx, const float* __restrict__ vy,
                                                        const uint8_t* __restrict__ kcnt, size_t n, size_t n_groups,
                                                        uint8_t* __restrict__ out, unsigned long long* __restrict__ d_count,
-                                                       unsigned long long* __restrict__ words, uint32_t* __restrict__ async_err)
+                                                       CountWs words, uint32_t* __restrict__ async_err)
 {
     uint32_t my_count = 0;
     bool any_bad = false;
@@ -320,12 +320,12 @@ __global__ __launch_bounds__(64) void sat_poly4_kernel(const float* __restrict__
 }
 
 // c2d_poly_binned.hip: a padded layout run as ONE bin of the binned kernel (its 12- and 16-row instances)
-int launch_poly_onebin(hipStream_t s, const float* d_vx, const float* d_vy, const uint8_t* d_k, size_t n, int rows, uint8_t* d_out,
-                       unsigned long long* d_count, unsigned long long* words2, uint32_t* async_err);
+int launch_poly_onebin(c2d_ctx* ctx, hipStream_t s, const float* d_vx, const float* d_vy, const uint8_t* d_k, size_t n, int rows, uint8_t* d_out,
+                       unsigned long long* d_count, uint32_t* async_err);
 
 template <int KM, int MIN_WAVES, bool FULL>
-static void launch_poly(hipStream_t s, const float* d_vx, const float* d_vy, const uint8_t* d_k, size_t n, int rows, uint8_t* d_out,
-                        unsigned long long* d_count, unsigned long long* words, uint32_t* async_err)
+static void launch_poly(c2d_ctx* ctx, hipStream_t s, const float* d_vx, const float* d_vy, const uint8_t* d_k, size_t n, int rows, uint8_t* d_out,
+                        unsigned long long* d_count, uint32_t* async_err)
 {
     // tiles per wave: 2 pay in the binned kernel (c2d_poly_binned.hip); here, at the HBM ceiling of the padded bytes, 2 and 4 change nothing
     // (config 5: 0.410 / 0.414 / 0.422 ms, K <= 8 in 8 rows: 0.264 / 0.265 / 0.270 ms)
@@ -335,7 +335,8 @@ static void launch_poly(hipStream_t s, const float* d_vx, const float* d_vy, con
     const size_t n_tiles = (n + 63) / 64;
     const size_t want = (n_tiles + C2D_POLY_PADDED_TILES_PER_WAVE - 1) / C2D_POLY_PADDED_TILES_PER_WAVE;  // the kernel strides by the grid
     const int grid = (int)(want < (size_t)kMaxGrid ? want : (size_t)kMaxGrid);
-    hipLaunchKernelGGL((sat_poly_kernel<KM, MIN_WAVES, FULL>), dim3(grid), dim3(64), 0, s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words, async_err);
+    hipLaunchKernelGGL((sat_poly_kernel<KM, MIN_WAVES, FULL>), dim3(grid), dim3(64), 0, s, d_vx, d_vy, d_k, n, rows, d_out, d_count,
+                       workspace_count_ticket2(ctx, s, (size_t)grid, d_count != nullptr), async_err);  // a wave per 64 pairs: the two-level count
 }
 
 }  // namespace c2d
@@ -355,25 +356,23 @@ int c2d_sat_poly_pairs_rows(c2d_ctx* ctx, const float* d_vx, const float* d_vy, 
     hipStream_t s = (hipStream_t)stream;
     if (int rc = workspace_acquire(ctx, s, d_count != nullptr)) return rc;
     uint32_t* err = ctx->d_async_err;
-    unsigned long long* words = ctx->d_count_words;     // sat_poly4_kernel: a wave per 256 pairs
-    unsigned long long* words2 = ctx->d_count_words2;   // sat_poly_kernel: a wave per 64 pairs (c2d_count.hpp)
     auto aligned = [](const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
     if (rows == 4 && n % 4 == 0 && aligned(d_vx, 16) && aligned(d_vy, 16) && aligned(d_k, 4) && aligned(d_out, 4)) {
         const size_t n_groups = n / 4;
         const size_t blocks = (n_groups + 63) / 64;
-        hipLaunchKernelGGL(sat_poly4_kernel, dim3((unsigned)(blocks < (size_t)kMaxGrid ? blocks : (size_t)kMaxGrid)), dim3(64), 0, s, d_vx, d_vy, d_k, n,
-                           n_groups, d_out, d_count, words, err);
-    } else if (rows == 16) launch_poly<16, 5, true>(s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words2, err);
+        const size_t grid = blocks < (size_t)kMaxGrid ? blocks : (size_t)kMaxGrid;
+        hipLaunchKernelGGL(sat_poly4_kernel, dim3((unsigned)grid), dim3(64), 0, s, d_vx, d_vy, d_k, n, n_groups, d_out, d_count,
+                           workspace_count_ticket(ctx, s, grid, d_count != nullptr), err);  // a wave per 256 pairs: the single-level count
+    } else if (rows == 16) launch_poly<16, 5, true>(ctx, s, d_vx, d_vy, d_k, n, rows, d_out, d_count, err);
     else if (rows > 8) {
         // 9..15 rows: the binned kernel's 12- / 16-row instances with the layout as ONE bin (all rows requested at once, straight-line
         // phase 1: 12-row layouts 0.330 instead of 0.368 ms per 1e7 pairs); planes of 4 GiB and more stay with the generic instance
-        if (launch_poly_onebin(s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words2, err) != C2D_OK)
-            launch_poly<16, 5, false>(s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words2, err);
+        if (launch_poly_onebin(ctx, s, d_vx, d_vy, d_k, n, rows, d_out, d_count, err) != C2D_OK)
+            launch_poly<16, 5, false>(ctx, s, d_vx, d_vy, d_k, n, rows, d_out, d_count, err);
     }
-    else if (rows > 4) launch_poly<8, 7, false>(s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words2, err);
-    else launch_poly<4, 8, false>(s, d_vx, d_vy, d_k, n, rows, d_out, d_count, words2, err);
+    else if (rows > 4) launch_poly<8, 7, false>(ctx, s, d_vx, d_vy, d_k, n, rows, d_out, d_count, err);
+    else launch_poly<4, 8, false>(ctx, s, d_vx, d_vy, d_k, n, rows, d_out, d_count, err);
     C2D_LAUNCH_CHECK(ctx);
-    workspace_release(ctx, s, d_count != nullptr);
     return C2D_OK;
 }
 

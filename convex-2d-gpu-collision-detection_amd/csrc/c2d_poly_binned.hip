@@ -325,7 +325,6 @@ C2D_DEV uint32_t binned_tile(const BinDesc& D, uint32_t tile_in_bin, uint32_t* _
     if (in) D.out[p0 + lane] = collide ? (uint8_t)1 : (uint8_t)0;
     return (uint32_t)__popcll(__ballot(collide));
 }
-static_assert(kCountWords2Bytes == C2D_COUNT_WORDS2_BYTES, "workspace size of the two-level count");
 
 // every bin of a batch in one launch: a u32 per tile names the bin
 // A wave takes kTilesPerWave consecutive tiles and arrives at the count once: with one tile per wave the returning atomic of the
@@ -340,7 +339,7 @@ static_assert(kCountWords2Bytes == C2D_COUNT_WORDS2_BYTES, "workspace size of th
 constexpr uint32_t kTilesPerWave = C2D_POLY_TILES_PER_WAVE;
 __global__ __launch_bounds__(64, 5) void sat_poly_binned_kernel(const BinDesc* __restrict__ bins, const uint32_t* __restrict__ tile_bin,
                                                                uint32_t tile_begin, uint32_t tile_end, unsigned long long* __restrict__ d_count,
-                                                               unsigned long long* __restrict__ words, uint32_t* __restrict__ async_err)
+                                                               CountWs words, uint32_t* __restrict__ async_err)
 {
     uint32_t total = 0;
 #pragma nounroll
@@ -357,15 +356,15 @@ __global__ __launch_bounds__(64, 5) void sat_poly_binned_kernel(const BinDesc* _
 
 // ONE bin whose descriptor travels in the kernel arguments: the padded layouts of c2d_sat_poly_pairs_rows (no table, no upload)
 __global__ __launch_bounds__(64, 5) void sat_poly_onebin_kernel(BinDesc D, uint32_t tile_offset, unsigned long long* __restrict__ d_count,
-                                                               unsigned long long* __restrict__ words, uint32_t* __restrict__ async_err)
+                                                               CountWs words, uint32_t* __restrict__ async_err)
 {
     const uint32_t c = binned_tile<true>(D, blockIdx.x + tile_offset, async_err);
     if (d_count) wave_count_arrive_total2(c, d_count, words);
 }
 
 // host entry used by c2d_poly.hip: rows_a == rows_b == rows, planes rows * n apart
-int launch_poly_onebin(hipStream_t s, const float* d_vx, const float* d_vy, const uint8_t* d_k, size_t n, int rows, uint8_t* d_out,
-                       unsigned long long* d_count, unsigned long long* words2, uint32_t* async_err)
+int launch_poly_onebin(c2d_ctx* ctx, hipStream_t s, const float* d_vx, const float* d_vy, const uint8_t* d_k, size_t n, int rows, uint8_t* d_out,
+                       unsigned long long* d_count, uint32_t* async_err)
 {
     if (n > 0xffffffffull || (uint64_t)rows * n * 4 > 0xffffffffull) return C2D_ERR_UNSUPPORTED;
     BinDesc D;
@@ -375,7 +374,8 @@ int launch_poly_onebin(hipStream_t s, const float* d_vx, const float* d_vy, cons
     const size_t tiles = (n + 63) / 64;
     for (size_t t0 = 0; t0 < tiles; t0 += (size_t)kMaxGrid) {
         const size_t grid = std::min(tiles - t0, (size_t)kMaxGrid);
-        hipLaunchKernelGGL(sat_poly_onebin_kernel, dim3((unsigned)grid), dim3(64), 0, s, D, (uint32_t)t0, d_count, words2, async_err);
+        hipLaunchKernelGGL(sat_poly_onebin_kernel, dim3((unsigned)grid), dim3(64), 0, s, D, (uint32_t)t0, d_count,
+                           workspace_count_ticket2(ctx, s, grid, d_count != nullptr), async_err);
     }
     return C2D_OK;
 }
@@ -937,10 +937,9 @@ int c2d_sat_poly_pairs_binned(c2d_ctx* ctx, const c2d_poly_bins* bins, unsigned 
         const size_t t1 = std::min(bins->n_tiles, t0 + per_launch);
         const size_t grid = (t1 - t0 + kTilesPerWave - 1) / kTilesPerWave;
         hipLaunchKernelGGL(sat_poly_binned_kernel, dim3((unsigned)grid), dim3(64), 0, s, bins->d_table, bins->d_tile_bin, (uint32_t)t0, (uint32_t)t1, d_count,
-                           ctx->d_count_words2, ctx->d_async_err);
+                           workspace_count_ticket2(ctx, s, grid, d_count != nullptr), ctx->d_async_err);
     }
     C2D_LAUNCH_CHECK(ctx);
-    workspace_release(ctx, s, d_count != nullptr);
     return C2D_OK;
 }
 
@@ -970,7 +969,14 @@ int c2d_poly_bins_from_padded(c2d_ctx* ctx, const float* d_vx, const float* d_vy
     B->device = ctx->device;
     B->n_input = n;
     if (n == 0) { *out = B; return C2D_OK; }
-    auto fail = [&](int st) { release(B); return st; };
+    // the pass uses the ctx scratch and ends synchronised; a failure after its first enqueue drains the stream before it
+    // returns, so nothing of the call stays in flight on the scratch (no ticket needed: c2d_internal.hpp)
+    bool enqueued = false;
+    auto fail = [&](int st) {
+        if (enqueued) { (void)hipStreamSynchronize(s); (void)hipGetLastError(); }
+        release(B);
+        return st;
+    };
 #define C2D_BIN_HIP(call)                                                                        \
     do {                                                                                         \
         hipError_t e__ = (call);                                                                 \
@@ -996,6 +1002,7 @@ int c2d_poly_bins_from_padded(c2d_ctx* ctx, const float* d_vx, const float* d_vy
     uint32_t* d_totals = d_hist + n_tiles * 256;
     uint32_t* d_chunk_sums = d_totals + 257;
     uint32_t hist[257];
+    enqueued = true;
     C2D_BIN_HIP(hipMemsetAsync(d_totals, 0, (257 + n_chunks * 256) * sizeof(uint32_t), s));
     hipLaunchKernelGGL(poly_bin_count_kernel, dim3((unsigned)n_tiles), dim3(kBinBlock), 0, s, d_k, n, rows, granularity, d_hist, d_chunk_sums, d_totals + 256);
     hipLaunchKernelGGL(poly_bin_scan_kernel, dim3((unsigned)n_chunks), dim3(256), 0, s, d_hist, (uint32_t)n_tiles, d_chunk_sums, d_totals);
@@ -1104,7 +1111,7 @@ int c2d_poly_bins_from_padded(c2d_ctx* ctx, const float* d_vx, const float* d_vy
     if (bytes < (16ull << 30)) hipLaunchKernelGGL(poly_bin_move_kernel<uint32_t>, dim3(A.tiles_per_xcd * 8u), dim3(kBinBlock), 0, s, A);  // (n < 2^32)
     else hipLaunchKernelGGL(poly_bin_move_kernel<uint64_t>, dim3(A.tiles_per_xcd * 8u), dim3(kBinBlock), 0, s, A);
     C2D_BIN_HIP(hipStreamSynchronize(s));  // (the host vectors above must outlive their copies)
-    workspace_release(ctx, s, true);
+    workspace_stream_drained(ctx, s);
     lap("move kernel");
 #undef C2D_BIN_HIP
     if (B->had_bad_counts) {

@@ -73,7 +73,7 @@ C2D_DEV uint32_t bits_to_bytes4(uint32_t b) { return (b & 1u) | ((b & 2u) << 7) 
 template <int VEC, int BLOCK>
 __global__ __launch_bounds__(BLOCK, (VEC == 4 ? 5 : 1)) void sat_rect_verts_kernel(Planes16 P, size_t first, size_t n_groups,
                                                                 uint8_t* __restrict__ out,
-                                                                unsigned long long* __restrict__ d_count, unsigned long long* __restrict__ words)
+                                                                unsigned long long* __restrict__ d_count, CountWs words)
 {
     uint32_t my_count = 0;
     const size_t stride = (size_t)gridDim.x * BLOCK;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(BLOCK, (VEC == 4 ? 5 : 1)) void sat_rect_verts_kern
 // 16-lane row assembles the word.  The plain form (one pair per lane, one ballot per wave) takes what is left.
 __global__ __launch_bounds__(64) void sat_rect_verts_mask4_kernel(Planes16 P, size_t n_groups, unsigned long long* __restrict__ mask,
                                                                   unsigned long long* __restrict__ d_count,
-                                                                  unsigned long long* __restrict__ words)
+                                                                  CountWs words)
 {
     const uint32_t lane = threadIdx.x;
     const size_t g = (size_t)blockIdx.x * 64 + lane;  // n_groups is a multiple of 16: a 16-lane row (one word) is all in or all out
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(64) void sat_rect_verts_mask4_kernel(Planes16 P, si
 
 __global__ __launch_bounds__(kBlock) void sat_rect_verts_mask1_kernel(Planes16 P, size_t first, size_t n, unsigned long long* __restrict__ mask,
                                                                       unsigned long long* __restrict__ d_count,
-                                                                      unsigned long long* __restrict__ words)
+                                                                      CountWs words)
 {
     // `first` is a multiple of 64 and every wave owns the 64 pairs of one word
     uint32_t my_count = 0;
@@ -177,7 +177,7 @@ template <bool OUT16>
 __global__ __launch_bounds__(64) void sat_rect_aos_kernel(const float* __restrict__ r1s, const float* __restrict__ r2s,
                                                          size_t n, uint8_t* __restrict__ out,
                                                          unsigned long long* __restrict__ d_count,
-                                                         unsigned long long* __restrict__ words)
+                                                         CountWs words)
 {
     // A wave owns 128 consecutive pairs = 4 KiB of r1 and 4 KiB of r2.  Lane i fetches the 16-byte chunks i, 64 + i,
     // 128 + i and 192 + i of each array (eight fully coalesced 1-KiB loads in flight per lane), the chunks go through a
@@ -310,7 +310,7 @@ template <int VEC, int BLOCK>
 __global__ __launch_bounds__(BLOCK, (VEC == 4 ? 5 : 1)) void sat_rect_pose_kernel(Planes10 P, size_t first, size_t n_groups,
                                                               uint8_t* __restrict__ out,
                                                               unsigned long long* __restrict__ d_count,
-                                                              unsigned long long* __restrict__ words)
+                                                              CountWs words)
 {
     uint32_t my_count = 0;
     const size_t stride = (size_t)gridDim.x * BLOCK;
@@ -457,17 +457,16 @@ int c2d_sat_rect_pairs_verts(c2d_ctx* ctx, const float* const d_planes[16], size
     if (n4) {
         const int grid = grid_for(n4, kWideBlock, kMaxBlocks);
         hipLaunchKernelGGL((sat_rect_verts_kernel<4, kWideBlock>), dim3(grid), dim3(kWideBlock), 0, s, P, (size_t)0, n4, d_out,
-                           d_count, ctx->d_count_words);
+                           d_count, workspace_count_ticket(ctx, s, (size_t)grid * (kWideBlock / 64), d_count != nullptr));
         C2D_LAUNCH_CHECK(ctx);
     }
     const size_t rest = n - 4 * n4;
     if (rest) {
         const int grid = grid_for(rest, kBlock, kMaxBlocks);
         hipLaunchKernelGGL((sat_rect_verts_kernel<1, kBlock>), dim3(grid), dim3(kBlock), 0, s, P, 4 * n4, rest, d_out, d_count,
-                           ctx->d_count_words);
+                           workspace_count_ticket(ctx, s, (size_t)grid * (kBlock / 64), d_count != nullptr));
         C2D_LAUNCH_CHECK(ctx);
     }
-    workspace_release(ctx, s, d_count != nullptr);
     return C2D_OK;
 }
 
@@ -496,16 +495,16 @@ int c2d_sat_rect_pairs_verts_mask(c2d_ctx* ctx, const float* const d_planes[16],
         for (int k = 0; k < 16; k++) Q.p[k] = P.p[k] + done;
         const size_t groups = words_left * 16;
         hipLaunchKernelGGL(sat_rect_verts_mask4_kernel, dim3((unsigned)((groups + 63) / 64)), dim3(64), 0, s, Q, groups, d_mask + done / 64, d_count,
-                           ctx->d_count_words);
+                           workspace_count_ticket(ctx, s, (groups + 63) / 64, d_count != nullptr));
         C2D_LAUNCH_CHECK(ctx);
         done += words_left * 64;
     }
     if (done < n) {
         const int grid = grid_for(n - done, kBlock, kMaxBlocks);
-        hipLaunchKernelGGL(sat_rect_verts_mask1_kernel, dim3(grid), dim3(kBlock), 0, s, P, done, n, d_mask, d_count, ctx->d_count_words);
+        hipLaunchKernelGGL(sat_rect_verts_mask1_kernel, dim3(grid), dim3(kBlock), 0, s, P, done, n, d_mask, d_count,
+                           workspace_count_ticket(ctx, s, (size_t)grid * (kBlock / 64), d_count != nullptr));
         C2D_LAUNCH_CHECK(ctx);
     }
-    workspace_release(ctx, s, d_count != nullptr);
     return C2D_OK;
 }
 
@@ -519,12 +518,12 @@ int c2d_sat_rect_pairs_aos(c2d_ctx* ctx, const float* d_r1, const float* d_r2, s
     DeviceGuard g(ctx->device);
     if (int rc = workspace_acquire(ctx, (hipStream_t)stream, d_count != nullptr)) return rc;
     const int grid = grid_for(n, 128, kMaxBlocks);  // one 128-pair tile per single-wave block
+    const CountWs ws = workspace_count_ticket(ctx, (hipStream_t)stream, (size_t)grid, d_count != nullptr);
     if (aligned_to(d_out, 2))
-        hipLaunchKernelGGL(sat_rect_aos_kernel<true>, dim3(grid), dim3(64), 0, (hipStream_t)stream, d_r1, d_r2, n, d_out, d_count, ctx->d_count_words);
+        hipLaunchKernelGGL(sat_rect_aos_kernel<true>, dim3(grid), dim3(64), 0, (hipStream_t)stream, d_r1, d_r2, n, d_out, d_count, ws);
     else
-        hipLaunchKernelGGL(sat_rect_aos_kernel<false>, dim3(grid), dim3(64), 0, (hipStream_t)stream, d_r1, d_r2, n, d_out, d_count, ctx->d_count_words);
+        hipLaunchKernelGGL(sat_rect_aos_kernel<false>, dim3(grid), dim3(64), 0, (hipStream_t)stream, d_r1, d_r2, n, d_out, d_count, ws);
     C2D_LAUNCH_CHECK(ctx);
-    workspace_release(ctx, (hipStream_t)stream, d_count != nullptr);
     return C2D_OK;
 }
 
@@ -548,17 +547,16 @@ int c2d_sat_rect_pairs_pose(c2d_ctx* ctx, const float* const d_pose_planes[10], 
     if (n4) {
         const int grid = grid_for(n4, kWideBlock, kMaxBlocks);
         hipLaunchKernelGGL((sat_rect_pose_kernel<4, kWideBlock>), dim3(grid), dim3(kWideBlock), 0, s, P, (size_t)0, n4, d_out,
-                           d_count, ctx->d_count_words);
+                           d_count, workspace_count_ticket(ctx, s, (size_t)grid * (kWideBlock / 64), d_count != nullptr));
         C2D_LAUNCH_CHECK(ctx);
     }
     const size_t rest = n - 4 * n4;
     if (rest) {
         const int grid = grid_for(rest, kBlock, kMaxBlocks);
         hipLaunchKernelGGL((sat_rect_pose_kernel<1, kBlock>), dim3(grid), dim3(kBlock), 0, s, P, 4 * n4, rest, d_out, d_count,
-                           ctx->d_count_words);
+                           workspace_count_ticket(ctx, s, (size_t)grid * (kBlock / 64), d_count != nullptr));
         C2D_LAUNCH_CHECK(ctx);
     }
-    workspace_release(ctx, s, d_count != nullptr);
     return C2D_OK;
 }
 

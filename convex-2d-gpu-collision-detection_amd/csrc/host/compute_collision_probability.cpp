@@ -35,10 +35,10 @@ struct Arguments {  // defaults: compute_collision_probability.cu:35-42
 // hit counts, p = hits / S.
 static int run_single_pair(const Arguments& a, const Shard& shard)
 {
-    c2d_ctx* ctx = nullptr;
-    C2D_CALL(ctx, c2d_ctx_create(shard.device, &ctx));
-    c2d_stream stream = nullptr;
-    C2D_CALL(ctx, c2d_stream_create(ctx, &stream));
+    CtxScope scope;   // ctx, stream, link buffer and device words are released on every way out
+    C2D_CALL(scope.ctx, scope.open(shard.device));
+    c2d_ctx* ctx = scope.ctx;
+    c2d_stream stream = scope.stream;
     DistLink link;
     C2D_CALL(ctx, link.open(ctx, shard));
     const unsigned long long S = a.pair_samples, W = static_cast<unsigned long long>(shard.world), r = static_cast<unsigned long long>(shard.rank);
@@ -48,6 +48,8 @@ static int run_single_pair(const Arguments& a, const Shard& shard)
     const Pose pose{a.pair_pose[0], a.pair_pose[1], a.pair_pose[2]};
     const StdDev sd{a.pair_std_dev[0], a.pair_std_dev[1], a.pair_std_dev[2], a.pair_std_dev[3], a.pair_std_dev[4]};
     void* d_hits = nullptr;
+    DeviceBuffers buffers(ctx);
+    buffers.own({&d_hits});
     C2D_CALL(ctx, c2d_malloc(ctx, &d_hits, sizeof(unsigned long long)));
     C2D_CALL(ctx, c2d_memset(ctx, d_hits, 0, sizeof(unsigned long long), stream));
     const auto t0 = std::chrono::steady_clock::now();
@@ -65,10 +67,9 @@ static int run_single_pair(const Arguments& a, const Shard& shard)
                     "\"seconds\": %.4f, \"rank_kernel_seconds\": %.4f, \"mc_samples_per_s\": %.4g}\n",
                     shard.rank, shard.world, w[2], link.active() ? c2d_dist_transport(link.dist) : "none", w[1], w[0],
                     w[1] ? static_cast<double>(w[0]) / static_cast<double>(w[1]) : 0.0, total_s, local_s, total_s > 0 ? w[1] / total_s : 0.0);
-    c2d_free(ctx, d_hits);
+    buffers.release();
     link.close();
-    c2d_stream_destroy(ctx, stream);
-    c2d_ctx_destroy(ctx);
+    scope.close();
     return 0;
 }
 
@@ -183,6 +184,8 @@ int main(int argc, char* argv[])
         start_batch_count = static_cast<int>(w[0]);
     }
     void *d_poses = nullptr, *d_sd = nullptr;
+    DeviceBuffers buffers(ctx);   // (declared after the slots that own the ctx: released before them on every way out)
+    buffers.own({&d_poses, &d_sd});
     C2D_CALL(ctx, c2d_malloc(ctx, &d_poses, poses.data.size() * sizeof(float)));
     C2D_CALL(ctx, c2d_malloc(ctx, &d_sd, std_devs.size() * sizeof(StdDev)));
     C2D_CALL(ctx, c2d_memcpy_h2d(ctx, d_poses, poses.data.data(), poses.data.size() * sizeof(float), stream));
@@ -265,7 +268,7 @@ int main(int argc, char* argv[])
         std::cout << "Elapsed time: " << std::chrono::duration_cast<std::chrono::minutes>(end - begin).count() << " [min]" << std::endl;
     }
     C2D_CALL(ctx, print_json_summary("compute_collision_probability", shard, stats, counter, &link, stream));
-    for (void* ptr : {d_poses, d_sd}) c2d_free(ctx, ptr);
+    buffers.release();
     link.close();
     for (auto& sl : slots) sl.close();
     if (chatty) std::cout << "Done." << std::endl;

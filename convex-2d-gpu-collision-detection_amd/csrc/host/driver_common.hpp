@@ -125,8 +125,18 @@ struct DistLink {
         // 0 = the library's default limit: $C2D_DIST_TIMEOUT_S, or 300 s
         int st = c2d_dist_init_file(ctx, sh.rank, sh.world, sh.id_file.c_str(), 0.0, &dist);
         if (st != C2D_OK) return st;
+        // one line per rank: which card, which RCCL — a multi-GPU record must be readable without guessing
+        c2d_device_info di;
+        char lib[1024] = "";
+        (void)c2d_dist_rccl_version(&rccl_version, lib, sizeof lib);
+        rccl_library = lib;
+        if (c2d_ctx_info(ctx, &di) == C2D_OK)
+            std::fprintf(stderr, "[c2d] rank %d of %d: device %d (%s, PCI %s), reduce: %s over %d ranks, RCCL %d from %s\n", sh.rank, sh.world, di.device,
+                         di.name, di.pci_bus_id[0] ? di.pci_bus_id : "?", c2d_dist_transport(dist), c2d_dist_world_size(dist), rccl_version, lib);
         return c2d_malloc(ctx, reinterpret_cast<void**>(&d_buf), kWords * sizeof(unsigned long long));
     }
+    int rccl_version = 0;
+    std::string rccl_library;
     bool active() const { return dist != nullptr; }
     // in-place sum over ranks of up to kWords host counters
     int sum(unsigned long long* h, size_t count, c2d_stream stream)
@@ -157,6 +167,55 @@ struct DistLink {
         d_buf = nullptr;
         dist = nullptr;
     }
+    // An error return from main() (C2D_CALL) releases the buffer; the communicator is left to the end of the process there:
+    // ncclCommDestroy after a failed run may wait for peers that are already gone.  The normal path calls close().
+    ~DistLink()
+    {
+        if (d_buf) c2d_free(ctx, d_buf);
+        d_buf = nullptr;
+    }
+};
+
+// What a driver's main() allocates through the C-ABI, released whichever way main() is left — C2D_CALL returns on the first
+// error.  Declare AFTER the ctx owner (BatchSlot slots / CtxScope): objects are destroyed in reverse order of declaration, and
+// the buffers must go before their ctx.
+struct DeviceBuffers {
+    c2d_ctx* ctx = nullptr;
+    std::vector<void**> owned;
+    explicit DeviceBuffers(c2d_ctx* c) : ctx(c) {}
+    DeviceBuffers(const DeviceBuffers&) = delete;
+    DeviceBuffers& operator=(const DeviceBuffers&) = delete;
+    void own(std::initializer_list<void**> ptrs) { owned.insert(owned.end(), ptrs.begin(), ptrs.end()); }
+    void release()
+    {
+        for (auto it = owned.rbegin(); it != owned.rend(); ++it)
+            if (**it) { c2d_free(ctx, **it); **it = nullptr; }
+    }
+    ~DeviceBuffers() { release(); }
+};
+
+// ctx + stream of a driver that runs without BatchSlots (ztest, the single-pair mode)
+struct CtxScope {
+    c2d_ctx* ctx = nullptr;
+    c2d_stream stream = nullptr;
+    CtxScope() = default;
+    CtxScope(const CtxScope&) = delete;
+    CtxScope& operator=(const CtxScope&) = delete;
+    int open(int device)
+    {
+        int st = c2d_ctx_create(device, &ctx);
+        if (st == C2D_OK) st = c2d_stream_create(ctx, &stream);
+        return st;
+    }
+    void close()
+    {
+        if (!ctx) return;
+        if (stream) c2d_stream_destroy(ctx, stream);
+        c2d_ctx_destroy(ctx);
+        ctx = nullptr;
+        stream = nullptr;
+    }
+    ~CtxScope() { close(); }
 };
 
 // Two batches in flight per rank.  A batch is: scenes on the device (sampled there, or uploaded), the adaptive loop,
@@ -197,6 +256,10 @@ struct BatchSlot {
         if (st == C2D_OK) st = c2d_memcpy_d2h(ctx, used, d_used, n * sizeof(uint32_t), stream);
         return st;
     }
+    BatchSlot() = default;
+    BatchSlot(const BatchSlot&) = delete;
+    BatchSlot& operator=(const BatchSlot&) = delete;
+    ~BatchSlot() { close(); }   // (an error return from main() leaves through here)
     void close()
     {
         if (!ctx) return;
@@ -272,7 +335,9 @@ inline int print_json_summary(const char* tool, const Shard& sh, RunStats st, in
 {
     const char* reduce = "none";
     int ranks = 1;
+    std::string rccl_json;
     if (link && link->active()) {
+        rccl_json = ", \"rccl_version\": " + std::to_string(link->rccl_version) + ", \"rccl_library\": \"" + link->rccl_library + "\"";
         unsigned long long w[9] = {st.samples, st.hits, st.scenes, st.cp_hist[0], st.cp_hist[1], st.cp_hist[2], st.cp_hist[3],
                                    static_cast<unsigned long long>(batches), 1ull};
         int rc = link->sum(w, 9, stream);
@@ -294,10 +359,10 @@ inline int print_json_summary(const char* tool, const Shard& sh, RunStats st, in
     }
     std::printf("{\"tool\": \"%s\", \"rank\": %d, \"world_size\": %d, \"aggregated_over_ranks\": %d, \"reduce\": \"%s\", \"batches\": %d, "
                 "\"scenes\": %llu, \"mc_samples\": %llu, \"hits\": %llu, \"pooled_probability\": %.9g, "
-                "\"seconds\": %.3f, \"mc_samples_per_s\": %.4g, \"cp_hist_bins\": [0, 0.001, 0.01, 0.1, 1], \"cp_hist\": [%llu, %llu, %llu, %llu]%s}\n",
+                "\"seconds\": %.3f, \"mc_samples_per_s\": %.4g, \"cp_hist_bins\": [0, 0.001, 0.01, 0.1, 1], \"cp_hist\": [%llu, %llu, %llu, %llu]%s%s}\n",
                 tool, sh.rank, sh.world, ranks, reduce, batches, st.scenes, st.samples, st.hits,
                 st.samples ? static_cast<double>(st.hits) / static_cast<double>(st.samples) : 0.0, st.seconds,
-                st.seconds > 0 ? st.samples / st.seconds : 0.0, st.cp_hist[0], st.cp_hist[1], st.cp_hist[2], st.cp_hist[3], extra_json.c_str());
+                st.seconds > 0 ? st.samples / st.seconds : 0.0, st.cp_hist[0], st.cp_hist[1], st.cp_hist[2], st.cp_hist[3], rccl_json.c_str(), extra_json.c_str());
     std::fflush(stdout);
     return C2D_OK;
 }

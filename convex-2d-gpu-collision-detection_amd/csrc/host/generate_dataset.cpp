@@ -153,6 +153,8 @@ int main(int argc, char* argv[])
     // run of the reference's serial loop.  Nothing is drawn or uploaded per rank on the host; rank 0 saves the two
     // tables (:300-332) from a download that runs beside the batches.
     void *d_var = nullptr, *d_poses = nullptr, *d_sd = nullptr;
+    DeviceBuffers buffers(ctx);   // (declared after the slots that own the ctx and before the saver thread that reads the tables:
+    buffers.own({&d_var, &d_poses, &d_sd});   //  on every way out the thread is joined first, the tables go next, the ctx last)
     bool var_made = false, poses_made = false;
     try {
         if (a.variance_dir.empty()) {
@@ -334,7 +336,7 @@ int main(int argc, char* argv[])
     clock.add("batches_waiting_for_gpu", wait_gpu_s);
     clock.add("batches_host_stats_shuffle_npy", host_batch_s);
     C2D_CALL(ctx, print_json_summary("generate_dataset", shard, stats, counter, &link, stream, clock.json()));
-    for (void* ptr : {d_var, d_poses, d_sd}) c2d_free(ctx, ptr);
+    buffers.release();
     link.close();
     for (auto& sl : slots) sl.close();
     if (chatty) std::cout << "Done." << std::endl;

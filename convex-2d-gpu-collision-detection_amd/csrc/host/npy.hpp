@@ -7,6 +7,8 @@
 // the reference ever reads or writes.
 #pragma once
 
+#include <unistd.h>
+
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -41,8 +43,12 @@ inline void save_f32(const std::string& path, const std::vector<size_t>& shape, 
     dict.append(pad, ' ');
     dict.push_back('\n');
     if (dict.size() > 65535) throw std::runtime_error("npy: header too long");
-    std::ofstream f(path, std::ios::binary | std::ios::trunc);
-    if (!f) throw std::runtime_error("npy: cannot open for writing: " + path);
+    // The file appears under its name only when it is complete (written beside it, then renamed): a run that dies in the
+    // middle — the drivers _exit() on a multi-GPU time-out while a table is still being saved — leaves no truncated
+    // poses.npy / variances.npy / batch file that a later run with --pose_dir / --variance_dir would load.
+    const std::string tmp = path + ".tmp." + std::to_string(static_cast<long long>(getpid()));
+    std::ofstream f(tmp, std::ios::binary | std::ios::trunc);
+    if (!f) throw std::runtime_error("npy: cannot open for writing: " + tmp);
     const unsigned char magic[8] = {0x93, 'N', 'U', 'M', 'P', 'Y', 1, 0};
     f.write(reinterpret_cast<const char*>(magic), 8);
     const uint16_t hl = static_cast<uint16_t>(dict.size());
@@ -50,7 +56,9 @@ inline void save_f32(const std::string& path, const std::vector<size_t>& shape, 
     f.write(reinterpret_cast<const char*>(hlb), 2);
     f.write(dict.data(), static_cast<std::streamsize>(dict.size()));
     f.write(reinterpret_cast<const char*>(data), static_cast<std::streamsize>(count * sizeof(float)));
-    if (!f) throw std::runtime_error("npy: write failed: " + path);
+    f.close();
+    if (!f) { std::remove(tmp.c_str()); throw std::runtime_error("npy: write failed: " + path); }
+    if (std::rename(tmp.c_str(), path.c_str()) != 0) { std::remove(tmp.c_str()); throw std::runtime_error("npy: cannot rename into place: " + path); }
 }
 
 inline std::string dict_value(const std::string& dict, const std::string& key)

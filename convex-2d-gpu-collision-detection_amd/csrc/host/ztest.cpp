@@ -91,11 +91,13 @@ int main(int argc, char* argv[])
     if (N == 0 || num_poses == 0 || num_variances == 0) { std::cerr << "error: empty input\n"; return EXIT_FAILURE; }
     std::vector<StdDev> std_devs = std_devs_from_variances(variances.data);
 
-    c2d_ctx* ctx = nullptr;
-    C2D_CALL(ctx, c2d_ctx_create(shard.device, &ctx));
-    c2d_stream stream = nullptr;
-    C2D_CALL(ctx, c2d_stream_create(ctx, &stream));
+    CtxScope scope;   // ctx, stream and (below) the device buffers are released on every way out of main()
+    C2D_CALL(scope.ctx, scope.open(shard.device));
+    c2d_ctx* ctx = scope.ctx;
+    c2d_stream stream = scope.stream;
     void *d_poses = nullptr, *d_sd = nullptr, *d_scenes = nullptr, *d_hits = nullptr, *d_used = nullptr, *d_rows = nullptr;
+    DeviceBuffers buffers(ctx);
+    buffers.own({&d_poses, &d_sd, &d_scenes, &d_hits, &d_used, &d_rows});
     C2D_CALL(ctx, c2d_malloc(ctx, &d_poses, poses.data.size() * sizeof(float)));
     C2D_CALL(ctx, c2d_malloc(ctx, &d_sd, std_devs.size() * sizeof(StdDev)));
     C2D_CALL(ctx, c2d_malloc(ctx, &d_scenes, N * sizeof(PositionWithVarAndPoseIdx)));
@@ -146,9 +148,8 @@ int main(int argc, char* argv[])
     std::cout << "Finished computation" << std::endl;
     std::cout << "Elapsed time: " << std::chrono::duration_cast<std::chrono::minutes>(end - begin).count() << " [min]" << std::endl;
     C2D_CALL(ctx, print_json_summary("ztest", shard, stats, 1, nullptr, stream));
-    for (void* ptr : {d_poses, d_sd, d_scenes, d_hits, d_used, d_rows}) c2d_free(ctx, ptr);
-    c2d_stream_destroy(ctx, stream);
-    c2d_ctx_destroy(ctx);
+    buffers.release();
+    scope.close();
     std::cout << "Done." << std::endl;
     return 0;
 }

@@ -19,6 +19,13 @@
  *     that use the workspace (c2d_mc_scenes; the SAT entry points when d_count != NULL)
  *     are ordered by their stream; issuing one on stream B while an earlier one on
  *     stream A has not finished returns C2D_ERR_UNSUPPORTED (use one ctx per stream).
+ *     Streams stay the caller's: c2d keeps no stream handle beyond the call it was given to
+ *     (the guard reads completion stamps that the kernels raise themselves, never the
+ *     runtime's view of a remembered stream), so a stream may be destroyed by any means at
+ *     any time after its calls were issued.  While a stream is being captured into a graph
+ *     the guard stands aside: the order of a graph's replays against other work on the same
+ *     ctx is the caller's to arrange.  Should a launch ever fail after it took its place in
+ *     the guard's bookkeeping, c2d_stream_synchronize on that stream resets it.
  *
  * Arithmetic contract (DESIGN.md §"Canonical arithmetic"): IEEE binary32,
  * round-to-nearest-even, no multiply-add contraction except where the spec
@@ -53,7 +60,7 @@ extern "C" {
 #endif
 
 #define C2D_VERSION_MAJOR 0
-#define C2D_VERSION_MINOR 4
+#define C2D_VERSION_MINOR 5
 
 /* ---- status codes ------------------------------------------------------ */
 #define C2D_OK 0
@@ -82,6 +89,7 @@ typedef struct c2d_device_info {
     int wavefront_size;
     int lds_bytes_per_cu;
     size_t hbm_bytes;
+    char pci_bus_id[32]; /* "0000:8b:00.0" (hipDeviceGetPCIBusId): which card of the node this ctx sits on */
 } c2d_device_info;
 
 /* ---- library / context --------------------------------------------------- */
@@ -405,7 +413,10 @@ int c2d_sample_scenes(c2d_ctx* ctx, const Pose* d_poses, uint32_t num_poses,
  * The reference's README (README.md:3) says its code "can easily be extended to handle arbitrary
  * convex 2D shapes"; its own functions stop at rectangles (sample_rectangle utils.cu:144-157,
  * convex_collide utils.cu:159-184).  These two entry points are that extension of c2d_mc_pair /
- * c2d_mc_scenes, with the same random stream, draw order, sample sharding and stopping rule:
+ * c2d_mc_scenes, with the same random stream, draw order, sample sharding and stopping rule.
+ * STATUS: c2d_mc_poly_* goes beyond the reference — the semantics below (notably "dw, dh scale the
+ * obstacle frame") are this build's own generalisation, pinned only by this build's own oracle and by
+ * the rectangle case; no reference code or fixture stands behind them.
  *
  *   robot     a polygon in its own frame, rotated by theta and moved to pos with the arithmetic of
  *             rot_trans_rectangle (utils.cu:132-142; ccp.cu:132-133);
@@ -520,6 +531,12 @@ int c2d_dist_init_file(c2d_ctx* ctx, int rank, int world_size, const char* path,
 int c2d_dist_rank(const c2d_dist* dist);
 int c2d_dist_world_size(const c2d_dist* dist); /* as counted by RCCL (ncclCommCount) */
 const char* c2d_dist_transport(const c2d_dist* dist);
+/* Which RCCL sums the counters: ncclGetVersion's code (22203 = 2.22.3) and the file the library was loaded from (dladdr;
+ * "" if unknown), so that a scaling record can be read without the logs.  Loads librccl if no c2d_dist_* call has yet.
+ * Inside a process that already holds a librccl.so.1 — PyTorch ships its own — the loader hands back THAT one (same
+ * soname), otherwise /opt/rocm's; both are plain RCCL and nothing else is ever used.  The rehearsal build reports
+ * version 0 and "file (rehearsal)". */
+int c2d_dist_rccl_version(int* version, char* path_out, size_t path_bytes);
 int c2d_dist_all_reduce_sum_u64(c2d_dist* dist, unsigned long long* d_buf, size_t count,
                                 c2d_stream stream);
 int c2d_dist_broadcast_u64(c2d_dist* dist, unsigned long long* d_buf, size_t count, int root,

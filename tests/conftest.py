@@ -58,4 +58,7 @@ def oracle():
     from oracle import cpu
 
     cpu.lib()
+    # the box's CPU share, not the host's thread count: a 1-GPU job gets 16 cores of a host with many more hardware threads, and
+    # an OpenMP team of the host's size on that quota turns every small oracle call into milliseconds of thread wake-ups
+    cpu.set_num_threads(cpu.usable_cores())
     return cpu

@@ -202,6 +202,37 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert out.returncode != 0 and not out.stdout.strip()
 
 
+def test_bench_with_four_ranks_sharing_the_device(tmp_path):
+    """The round-end driver runs `bench.py --gpus 8` on a box this build never sees.  The pool lets at most six processes hold one
+    card open — the test runner is one, torch's launcher another — so the largest rehearsal INSIDE the suite is four ranks sharing
+    the device (gloo rendezvous, the file transport of the rehearsal build; profiles/r05_rehearse.sh runs five and six outside it):
+    one JSON line, four ranks in the reduce, and the sharding identities of DESIGN.md §7 — the ranks' Monte-Carlo sample ranges
+    and scene ranges are exactly the one-rank run over N times the range, so probabilities and totals are EQUAL."""
+    N = 4
+    small = ["--steps", "3", "--warmup", "1", "--pairs", "400000", "--mc-reps", "1", "--scenes-max-samples", "3000", "--poly-pairs", "100000",
+             "--poly-reps", "2", "--poly-scenes", "0", "--no-cpu-baseline", "--prewarm-ms", "5", "--no-pose"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(N), "--share-device", "--backend", "gloo",
+                          "--mc-samples", "1000000", "--scenes", "10000"] + small, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == N and j["config"]["ranks_in_reduce"] == N and "rehearsal" in j["config"]["reduce"]
+    assert j["config"]["rccl_version"] == 0 and j["config"]["rccl_library"] == "file (rehearsal)" and j["config"]["torch_backend"] == "gloo"
+    for r in range(N):  # every rank said which card it sits on
+        assert f"[bench] rank {r} of {N}: device 0" in out.stderr, out.stderr[-3000:]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mc-samples", str(N * 1000000), "--scenes", str(N * 10000)] + small,
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert one.returncode == 0, one.stderr[-3000:]
+    j1 = json.loads(one.stdout.strip().splitlines()[-1])
+    assert j1["n_gpus"] == 1 and j1["config"]["ranks_in_reduce"] == 1
+    assert j["mc"]["probability"] == j1["mc"]["probability"]                               # hits over [0, N S) either way
+    assert j["scenes"]["pooled_hit_fraction"] == j1["scenes"]["pooled_hit_fraction"]       # scene ids [0, N n) either way
+    assert j["scenes"]["mean_samples_per_point"] == j1["scenes"]["mean_samples_per_point"]
+    assert j["scenes"]["fixed_samples"]["pooled_hit_fraction"] == j1["scenes"]["fixed_samples"]["pooled_hit_fraction"]
+
+
 def test_c2d_dist_error_paths(eng, pkg, tmp_path):
     """A rank that never finds its peers gets C2D_ERR_DIST within the timeout instead of hanging; bad arguments are refused."""
     import time

@@ -26,3 +26,36 @@ def test_host_helpers_under_asan_ubsan(tmp_path):
     out = subprocess.run([str(exe), str(tmp_path)], capture_output=True, text=True, env=ENV)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr
+
+
+def _tsan_compiler():
+    """ThreadSanitizer of the ROCm LLVM: gcc 11's libtsan does not intercept pthread_cond_clockwait (what libstdc++'s
+    condition_variable::wait_for on the steady clock calls), loses track of the mutex across the wait and reports a
+    "double lock" plus a race between two accesses that both hold that mutex."""
+    for cxx in ("/opt/rocm/lib/llvm/bin/clang++", "clang++"):
+        try:
+            if subprocess.run([cxx, "--version"], capture_output=True).returncode == 0:
+                return cxx
+        except OSError:
+            pass
+    return None
+
+
+def test_watchdog_under_tsan(tmp_path):
+    """csrc/c2d_watchdog.hpp (the deadline mechanics of c2d_dist.hip, free of HIP and RCCL): in-time completion, a time-out whose
+    helper finishes later, the caller tearing its state down right after a time-out — clean under -fsanitize=thread; and the
+    variant with the defect planted (the helper writes the caller's ctx) IS reported, so a clean run means something."""
+    cxx = _tsan_compiler()
+    assert cxx, "no clang++ for the ThreadSanitizer build"
+    inc = "-I" + os.path.join(ROOT, "convex-2d-gpu-collision-detection_amd", "csrc")
+    src = os.path.join(ROOT, "tests", "cpp", "test_watchdog.cpp")
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0:report_thread_leaks=0")
+    exe = tmp_path / "test_watchdog_tsan"
+    subprocess.run([cxx, "-std=c++17", "-fsanitize=thread", "-g", "-O1", "-pthread", inc, src, "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0 and "watchdog ok" in out.stdout, out.stdout + out.stderr
+    assert "ThreadSanitizer" not in out.stderr, out.stderr
+    racy = tmp_path / "test_watchdog_tsan_planted"
+    subprocess.run([cxx, "-std=c++17", "-fsanitize=thread", "-g", "-O1", "-pthread", "-DWATCHDOG_TEST_PLANT_RACE", inc, src, "-o", str(racy)], check=True)
+    out = subprocess.run([str(racy)], capture_output=True, text=True, env=env, timeout=300)
+    assert "ThreadSanitizer: data race" in out.stderr or "ThreadSanitizer: heap-use-after-free" in out.stderr, out.stdout + out.stderr
