@@ -43,6 +43,8 @@ clean:
 # developer tools (not shipped in libc2d.so)
 TOOLS := $(CSRC)/tools/sat_tune $(CSRC)/tools/pose_probe $(CSRC)/tools/clock_probe $(CSRC)/tools/instr_probe $(CSRC)/tools/store_pattern_probe $(CSRC)/tools/stream_lifetime_probe
 tools: $(TOOLS)
+# (the instruction probe includes the Monte-Carlo legs' mixes when profiles/valu_issue.py has generated them)
+$(CSRC)/tools/instr_probe: $(wildcard $(CSRC)/tools/instr_probe_mixes.inc)
 $(CSRC)/tools/%: $(CSRC)/tools/%.hip $(HDRS)
 	$(HIPCC) -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -Iinclude $< -o $@
 

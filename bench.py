@@ -81,6 +81,24 @@ def held_clock(roofline: dict, c: dict) -> None:
     roofline["held_clock_source"] = "recorded, not measured in this run: %s" % c.get("held_clock_source")
 
 
+SIMDS = 256 * 4
+
+
+def issue_weighted(roofline: dict, c: dict, wave_instr_per_s: float) -> None:
+    """The 2-ticks-per-instruction VALU peak is not a roof any real mix reaches, and single-type instruction prices do not add
+    (profiles/valu_issue.py).  Where the collection has measured the rate of this leg's OWN instruction mix as a dependency-free
+    stream (csrc/tools/instr_probe, `mix <entry>` lines) and the clock build the clock the kernel holds, the roofline also carries
+    the fraction of the issue ticks the chip had that this mix needs: wave instructions/s x ticks per wave instruction of the mix
+    / (1024 SIMDs x held clock)."""
+    ticks, ghz = c.get("issue_ticks_per_wave_instr"), c.get("held_clock_ghz")
+    if not ticks or not ghz:
+        return
+    roofline["issue_ticks_per_wave_instr"] = ticks
+    roofline["frac_issue_weighted"] = round(wave_instr_per_s * ticks / (SIMDS * ghz * 1e9), 4)
+    roofline["issue_weighted_source"] = ("recorded, not measured in this run: the leg's instruction mix (per-type PMC counts x static mix of the loop code) as a "
+                                         "dependency-free stream in csrc/tools/instr_probe, %s; clock: held_clock_ghz" % c.get("source"))
+
+
 def self_launch(n_gpus: int) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks as fresh processes.  This parent has not
     imported torch and never touches a GPU; it relays rank 0's JSON line and the children's exit status."""
@@ -576,6 +594,7 @@ def main() -> None:
                               "frac": round(lane_ops / VALU_PEAK_TLANE, 4), "valu_instr_per_sample": c["valu_instr_per_sample"],
                               "instr_source": c.get("source")}
             held_clock(mc["roofline"], c)
+            issue_weighted(mc["roofline"], c, S / (mc_kernel_ms * 1e-3) * c["valu_instr_per_sample"] / 64)
 
     # ---- Monte-Carlo over convex polygons (README.md:3 "arbitrary convex 2D shapes"; include/c2d.h c2d_mc_poly_pair) -------------
     mc_poly = None
@@ -616,6 +635,7 @@ def main() -> None:
                                    "unit": "T VALU lane-instr/s per GPU", "frac": round(lane_ops / VALU_PEAK_TLANE, 4),
                                    "valu_instr_per_sample": c["valu_instr_per_sample"], "instr_source": c.get("source")}
             held_clock(mc_poly["roofline"], c)
+            issue_weighted(mc_poly["roofline"], c, PS / (mc_poly_ms * 1e-3) * c["valu_instr_per_sample"] / 64)
         # the adaptive loop over a dataset of polygon scenes (c2d_mc_poly_scenes): random obstacle polygons of 3..16 vertices, a 9-gon
         # robot, the stop rule of config 4.  Scenes shard over ranks like config 4's (scene_id_base = the shard's first scene).
         PN = args.poly_scenes
@@ -651,6 +671,8 @@ def main() -> None:
                                                  "peak": VALU_PEAK_TLANE, "unit": "T VALU lane-instr/s per GPU", "frac": round(lane_ops / VALU_PEAK_TLANE, 4),
                                                  "valu_instr_per_sample": cq["valu_instr_per_sample"], "instr_source": cq.get("source"),
                                                  "note": "instructions per DRAWN sample, as for config 4"}
+                held_clock(mc_poly["scenes"]["roofline"], cq)
+                issue_weighted(mc_poly["scenes"]["roofline"], cq, p_total / pqel * cq["valu_instr_per_sample"] / 64)
             mc_poly_scenes_keep = (pp_tab, ps_tab, p_scn, p_rob9, d_ph.get(), d_pu.get(), rank * PN)
             for a_ in (d_pp, d_ps, d_pscn, d_ph, d_pu):
                 a_.free()
@@ -711,6 +733,7 @@ def main() -> None:
                                       "note": "instructions per DRAWN sample: most samples of this workload are certain misses decided from "
                                               "their radius word, four words per Philox block (DESIGN.md §5); ~0 HBM bytes per sample"}
             held_clock(scenes_leg["roofline"], c)
+            issue_weighted(scenes_leg["roofline"], c, local_total / (loop_ms * 1e-3) * c["valu_instr_per_sample"] / 64)
             if c.get("evaluated_fraction"):
                 scenes_leg["evaluated_samples_per_s"] = float(hsum[1].item()) / sel * c["evaluated_fraction"]
                 scenes_leg["evaluated_fraction"] = c["evaluated_fraction"]

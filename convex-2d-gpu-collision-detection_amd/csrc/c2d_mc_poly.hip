@@ -37,7 +37,17 @@ __device__ unsigned long long c2d_mc_poly_stats_words[12];
 namespace c2d {
 
 constexpr int KM = C2D_POLY_KMAX;
-constexpr int kSurvSlots = 128;  // < 64 left over + at most 64 pushed by one evaluation pass
+#ifndef C2D_MC_POLY_IN_PLACE
+#define C2D_MC_POLY_IN_PLACE 48  // survivors of a pass from which stage B runs in place: the queue (two LDS round trips and the vertices
+#endif                           // built a second time) costs more than the idle lanes it would fill (32 / 40 / 48: profiles/notes_r04_mc_poly.md)
+// Survivor queue: at most 63 left over + at most C2D_MC_POLY_IN_PLACE - 1 pushed by one evaluation pass (a pass with more
+// survivors goes on in place).  112 slots instead of round 4's 128 bring the wave's LDS block from 8 208 to 7 824 bytes, so that
+// the 20 single-wave blocks per CU that __launch_bounds__(64, 5) asks for fit the 160 KB (round 4: 19).
+#ifndef C2D_MC_POLY_SURV_SLOTS
+#define C2D_MC_POLY_SURV_SLOTS ((64 + C2D_MC_POLY_IN_PLACE + 15) / 16 * 16)
+#endif
+constexpr int kSurvSlots = C2D_MC_POLY_SURV_SLOTS;
+static_assert(63 + C2D_MC_POLY_IN_PLACE - 1 < kSurvSlots, "survivor queue too small for a full push");
 
 // wave-uniform description of a polygon scene; the bulk lives in PolyQueue
 struct PolyScene {
@@ -313,9 +323,6 @@ C2D_DEV unsigned long long poly_stage_obstacle(const PolyScene& sc, const PolyQu
 
 // STAGE = 0: both stages in place (the plain path); 1: stage A, and stage B in place when most of the pass survives (`final`
 // says which: true = the returned lanes are the colliding ones, false = they are stage A's survivors); 2: stage B only.
-#ifndef C2D_MC_POLY_IN_PLACE
-#define C2D_MC_POLY_IN_PLACE 48  // survivors of a pass from which stage B runs in place: the queue (two LDS round trips and the vertices
-#endif                           // built a second time) costs more than the idle lanes it would fill (32 / 40 / 48: profiles/notes_r04_mc_poly.md)
 template <int CB, bool NANS, int STAGE>
 C2D_DEV unsigned long long poly_sample_stage(const PolyScene& sc, const PolyQueue& q, float dx, float dy, float c, float s, float fx, float fy,
                                              unsigned long long lanes, bool& final)

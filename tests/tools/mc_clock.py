@@ -46,6 +46,23 @@ def scenes(eng, ns, max_samples):
     return c
 
 
+def poly_scenes(eng, n):
+    """bench.py's adaptive polygon sub-leg (mc_poly.scenes)"""
+    pp, ps = wl.random_poly_tables(4096, 4096, seed=7)
+    scn = wl.random_poly_scenes(n, pp, ps, 2.3, seed=8)
+    rob = wl.mc_poly_pair_scene(9, 5)["robot"]
+    d_pp, d_ps, d_sc = eng.to_device(pp), eng.to_device(ps), eng.to_device(scn)
+    d_h, d_u = eng.zeros(n, np.uint32), eng.zeros(n, np.uint32)
+    run = lambda: eng.mc_poly_scenes(rob, d_pp, len(pp), d_ps, len(ps), d_sc, n, wl.DEFAULT_BINS, wl.DEFAULT_BIN_ACCURACY, 120_000, 11, 0, d_h, d_u, None)  # noqa: E731
+    run()  # warm
+    clock(eng, 1, poly=True)
+    run()
+    c = clock(eng, 1, poly=True)
+    for a in (d_pp, d_ps, d_sc, d_h, d_u):
+        a.free()
+    return c
+
+
 def main():
     eng = pkg.Engine(0, lib_path=LIB)
     sc = wl.MC_PAIR_SCENE
@@ -72,17 +89,19 @@ def main():
     print(f"config 4 shard (mc_scenes_advance_kernel, 4e6 data points, max_samples 120 000): {c4['waves']} waves, held {c4['ghz']:.3f} GHz")
     cd = scenes(eng, 100_000, 4_020_000)
     print(f"reference-default batch (1e5 data points, max_samples 4 020 000): {cd['waves']} waves, held {cd['ghz']:.3f} GHz")
+    cq = poly_scenes(eng, 200_000)
+    print(f"adaptive polygon scenes (mc_poly_scenes_advance_kernel, 2e5 scenes, max_samples 120 000): {cq['waves']} waves, held {cq['ghz']:.3f} GHz")
     if "--record" in sys.argv:
         tag = next((a for a in sys.argv[1:] if not a.startswith("--")), "")
         path = os.path.join(ROOT, "profiles", "measured_counts.json")
         cur = json.load(open(path))
-        for key, c in (("mc_pair.config3", c3), ("mc_poly_pair.bench", cp), ("mc_scenes.config4", c4)):
+        for key, c in (("mc_pair.config3", c3), ("mc_poly_pair.bench", cp), ("mc_scenes.config4", c4), ("mc_poly_scenes.bench", cq)):
             if key in cur:
                 cur[key]["held_clock_ghz"] = round(c["ghz"], 3)
                 cur[key]["held_clock_source"] = ("tests/tools/mc_clock.py on the clock build (make lib-mcclock): s_memtime / s_memrealtime stamps around the "
                                                  "sample work of %d waves%s" % (c["waves"], (", " + tag) if tag else ""))
         json.dump(cur, open(path, "w"), indent=1)
-        print("recorded", {k: cur[k].get("held_clock_ghz") for k in ("mc_pair.config3", "mc_poly_pair.bench", "mc_scenes.config4") if k in cur})
+        print("recorded", {k: cur[k].get("held_clock_ghz") for k in ("mc_pair.config3", "mc_poly_pair.bench", "mc_scenes.config4", "mc_poly_scenes.bench") if k in cur})
     eng.close()
 
 
