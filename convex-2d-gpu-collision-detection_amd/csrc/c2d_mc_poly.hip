@@ -36,6 +36,9 @@ __device__ unsigned long long c2d_mc_poly_stats_words[12];
 
 namespace c2d {
 
+#ifndef C2D_MC_POLY_PLAIN_PAIR_LOOP
+#define C2D_MC_POLY_PLAIN_PAIR_LOOP 0   // (A/B switch, round 5: the loop over the robot's vertex pairs without the one-ahead read)
+#endif
 constexpr int KM = C2D_POLY_KMAX;
 #ifndef C2D_MC_POLY_IN_PLACE
 #define C2D_MC_POLY_IN_PLACE 48  // survivors of a pass from which stage B runs in place: the queue (two LDS round trips and the vertices
@@ -285,8 +288,12 @@ C2D_DEV unsigned long long poly_stage_obstacle(const PolyScene& sc, const PolyQu
         // above ka repeat vertex 0, which is neutral, so an odd count reads one slot more)
         const float4* rv2 = reinterpret_cast<const float4*>(q.rvert);  // (x0, y0, x1, y1)
         const int pairs = (ka + 1) >> 1;
+#if C2D_MC_POLY_PLAIN_PAIR_LOOP
+        float4 cur = rv2[0];
+#else
         float4 cur = rv2[0];
         float4 nxt = rv2[pairs > 1 ? 1 : 0];
+#endif
 #pragma unroll
         for (int a = 0; a < G; a++) {
             r0[a] = nx[a] * cur.x + ny[a] * cur.y;
@@ -296,8 +303,12 @@ C2D_DEV unsigned long long poly_stage_obstacle(const PolyScene& sc, const PolyQu
         }
 #pragma nounroll
         for (int j = 1; j < pairs; j++) {
+#if C2D_MC_POLY_PLAIN_PAIR_LOOP
+            cur = rv2[j];
+#else
             cur = nxt;
             nxt = rv2[j + 1 < pairs ? j + 1 : j];  // (the last step reads its own pair again)
+#endif
 #pragma unroll
             for (int a = 0; a < G; a++) {
                 const float p0 = nx[a] * cur.x + ny[a] * cur.y, p1 = nx[a] * cur.z + ny[a] * cur.w;
@@ -317,7 +328,7 @@ C2D_DEV unsigned long long poly_stage_obstacle(const PolyScene& sc, const PolyQu
     if constexpr (CB >= 8) { group(integral_constant<int, 4>{}, integral_constant<int, 4>{}); if ((lanes & ~sep) == 0ull) return 0ull; }
     if constexpr (CB >= 12) { group(integral_constant<int, 4>{}, integral_constant<int, 8>{}); if ((lanes & ~sep) == 0ull) return 0ull; }
     if constexpr (CB >= 16) { group(integral_constant<int, 4>{}, integral_constant<int, 12>{}); if ((lanes & ~sep) == 0ull) return 0ull; }
-    if constexpr (CB % 4 == 2) group(integral_constant<int, 2>{}, integral_constant<int, CB - 2>{});
+    if constexpr (CB % 4 != 0) group(integral_constant<int, CB % 4>{}, integral_constant<int, CB - CB % 4>{});
     return lanes & ~sep;
 }
 
@@ -346,17 +357,46 @@ template <bool NANS, int STAGE>
 C2D_DEV unsigned long long poly_sample_stage_any(const PolyScene& sc, const PolyQueue& q, float dx, float dy, float c, float s, float fx, float fy,
                                                  unsigned long long lanes, bool& final)
 {
-    const int cls = (sc.kb + 1) >> 1;  // wave-uniform: vertex slots in registers = kb rounded up to an even number
-    switch (cls) {
-    case 1: return poly_sample_stage<2, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes, final);
-    case 2: return poly_sample_stage<4, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes, final);
-    case 3: return poly_sample_stage<6, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes, final);
-    case 4: return poly_sample_stage<8, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes, final);
-    case 5: return poly_sample_stage<10, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes, final);
-    case 6: return poly_sample_stage<12, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes, final);
-    case 7: return poly_sample_stage<14, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes, final);
-    default: return poly_sample_stage<16, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes, final);
+    // wave-uniform dispatch on the obstacle's vertex count.  The tame path holds EXACTLY kb vertex slots in registers (round 5: 16
+    // instances; rounded up to an even number before, a 5-gon paid for a sixth vertex in every projection loop and for a sixth,
+    // zero-length edge normal in stage B — 13 % of the bench scene's instructions).  The all-bit-patterns path keeps the eight
+    // even classes: its padding slot repeats vertex 0, which is exactly neutral, and it is there to be right, not fast.
+#ifndef C2D_MC_POLY_EVEN_SLOTS
+#define C2D_MC_POLY_EVEN_SLOTS 0   // 1: round 4's dispatch everywhere (A/B builds only)
+#endif
+#define C2D_POLY_STAGE(CB) return poly_sample_stage<CB, NANS, STAGE>(sc, q, dx, dy, c, s, fx, fy, lanes, final)
+    if constexpr (NANS || C2D_MC_POLY_EVEN_SLOTS) {
+        switch ((sc.kb + 1) >> 1) {
+        case 1: C2D_POLY_STAGE(2);
+        case 2: C2D_POLY_STAGE(4);
+        case 3: C2D_POLY_STAGE(6);
+        case 4: C2D_POLY_STAGE(8);
+        case 5: C2D_POLY_STAGE(10);
+        case 6: C2D_POLY_STAGE(12);
+        case 7: C2D_POLY_STAGE(14);
+        default: C2D_POLY_STAGE(16);
+        }
+    } else {
+        switch (sc.kb) {
+        case 1: C2D_POLY_STAGE(1);
+        case 2: C2D_POLY_STAGE(2);
+        case 3: C2D_POLY_STAGE(3);
+        case 4: C2D_POLY_STAGE(4);
+        case 5: C2D_POLY_STAGE(5);
+        case 6: C2D_POLY_STAGE(6);
+        case 7: C2D_POLY_STAGE(7);
+        case 8: C2D_POLY_STAGE(8);
+        case 9: C2D_POLY_STAGE(9);
+        case 10: C2D_POLY_STAGE(10);
+        case 11: C2D_POLY_STAGE(11);
+        case 12: C2D_POLY_STAGE(12);
+        case 13: C2D_POLY_STAGE(13);
+        case 14: C2D_POLY_STAGE(14);
+        case 15: C2D_POLY_STAGE(15);
+        default: C2D_POLY_STAGE(16);
+        }
     }
+#undef C2D_POLY_STAGE
 }
 
 // the rest of a sample after its centre: dtheta, dw, dh (utils.cu:148-150) -> rotation and the two scale factors.  The third
