@@ -345,6 +345,7 @@ def main() -> None:
     if use_dist:
         warm = torch.zeros(1, dtype=torch.int64, device=dev)
         all_reduce_sum(warm)
+        torch.cuda.synchronize()  # (two communicators live in this process — c2d's and torch's: never a collective of each in flight at once)
         dist.barrier()
         torch.cuda.synchronize()
 

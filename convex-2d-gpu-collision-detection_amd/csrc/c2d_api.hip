@@ -5,19 +5,18 @@
 
 namespace c2d {
 
-__global__ void workspace_stamp_kernel(unsigned long long* stamp, unsigned long long ticket) { atomicMax(stamp, ticket); }
+__global__ void workspace_stamp_kernel(unsigned long long* stamp, unsigned ticket) { atomicMax(reinterpret_cast<unsigned*>(stamp), ticket); }
 
 void workspace_stamp_behind(c2d_ctx* ctx, hipStream_t s)
 {
     if (stream_is_capturing(s)) return;
-    const unsigned long long ticket = ctx->ws_ticket + 1;
+    const unsigned ticket = workspace_next_ticket(ctx);
     hipLaunchKernelGGL(workspace_stamp_kernel, dim3(1), dim3(1), 0, s, ctx->d_ws_stamps + kStampOther, ticket);
     if (hipGetLastError() != hipSuccess) {   // nothing of the call may stay in flight behind an unarmed guard
         (void)hipStreamSynchronize(s);
         (void)hipGetLastError();
         return;
     }
-    ctx->ws_ticket = ticket;
     ctx->ws_expect[kStampOther] = ticket;
     ctx->ws_stream = s;
     ctx->ws_outstanding = true;

@@ -29,7 +29,10 @@ constexpr size_t kCountWords2Bytes = (size_t)kCountWords1 * 64 + (size_t)kCountW
 // second level of the two-level form, 1 for the calls that stamp with a kernel of their own (the adaptive Monte-Carlo
 // schedule).  A launch carries a ticket; the wave that completes a word raises that word's stamp to the ticket, so the host
 // can tell "everything this ctx launched on its workspace has retired" from the stamps alone — without asking the runtime
-// about a stream handle whose lifetime belongs to the caller.  Ticket 0 = no stamping (graph capture).
+// about a stream handle whose lifetime belongs to the caller.  Ticket 0 = no stamping (graph capture).  The ticket travels as 32
+// bits: a 64-bit kernel argument cost sat_poly_kernel<16, 5, true> — at its limit of scalar registers — two spilled SGPRs, through
+// them two VGPRs in scratch, and 8 % of its run time (430 -> 465 us per 1e7 pairs, profiles/r05a_kernel_stats.csv); the host handles
+// the wrap every 2^32 launches (c2d_internal.hpp).
 constexpr uint32_t kStampOther = kCountWords + kCountWords2;   // index of the extra stamp
 constexpr uint32_t kStampSlots = kStampOther + 1;
 constexpr size_t kWorkspaceStampsOffset = kCountWordsBytes + kCountWords2Bytes;           // bytes from the start of the block
@@ -37,7 +40,7 @@ constexpr size_t kWorkspaceBytes = kWorkspaceStampsOffset + (size_t)kStampSlots 
 
 struct CountWs {
     unsigned long long* words;   // the single-level words (block + 0) or the two-level words (block + kCountWordsBytes)
-    unsigned long long ticket;
+    unsigned ticket;
 };
 
 // The stamp is ONE relaxed, non-returning atomic behind the word's clearing — no fence between the two.  A release fence there
@@ -51,14 +54,14 @@ struct CountWs {
 #ifndef C2D_WS_STAMP_MODE
 #define C2D_WS_STAMP_MODE 1
 #endif
-C2D_DEV void stamp_raise(unsigned long long* stamp, unsigned long long ticket)
+C2D_DEV void stamp_raise(unsigned long long* stamp, unsigned ticket)
 {
 #if C2D_WS_STAMP_MODE > 0
     if (ticket) {
 #if C2D_WS_STAMP_MODE > 1
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 #endif
-        atomicMax(stamp, ticket);
+        atomicMax(reinterpret_cast<unsigned*>(stamp), ticket);   // (the low word of the 64-bit slot; the high word stays 0)
     }
 #endif
 }

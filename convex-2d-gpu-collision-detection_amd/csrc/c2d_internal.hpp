@@ -40,8 +40,8 @@ struct c2d_ctx {
     // destroyed it.
     hipStream_t ws_stream = nullptr;
     bool ws_outstanding = false;                    // tickets were issued (on ws_stream) that no check has seen retired yet
-    unsigned long long ws_ticket = 0;               // the last ticket handed out
-    unsigned long long ws_expect[c2d::kStampSlots] = {};  // per stamp: the ticket it must have reached
+    unsigned ws_ticket = 0;                         // the last ticket handed out (32 bits: workspace_next_ticket handles the wrap)
+    unsigned ws_expect[c2d::kStampSlots] = {};      // per stamp: the ticket it must have reached
     hipStream_t ws_probe_stream = nullptr;          // the guard's own stream and page-locked copy of the workspace block (words and
     unsigned long long* h_ws_block = nullptr;       // stamps), made at the first check that needs them
     mutable std::string last_error;
@@ -152,13 +152,27 @@ inline int workspace_acquire(c2d_ctx* ctx, hipStream_t s, bool uses)
     return C2D_OK;
 }
 
+// The next ticket.  Tickets are 32 bits and only ever compared by magnitude, so when they run out — every 2^32 launches — the
+// device is drained once, stamps and expectations go back to zero and counting starts again at 1.
+inline unsigned workspace_next_ticket(c2d_ctx* ctx)
+{
+    if (ctx->ws_ticket == 0xffffffffu) {
+        (void)hipDeviceSynchronize();
+        (void)hipMemset(ctx->d_ws_stamps, 0, kStampSlots * sizeof(unsigned long long));
+        std::memset(ctx->ws_expect, 0, sizeof ctx->ws_expect);
+        ctx->ws_outstanding = false;
+        ctx->ws_ticket = 0;
+    }
+    return ++ctx->ws_ticket;
+}
+
 // the ticket of one launch whose waves count through the single-level words / the two-level words; call it right before the
 // launch on stream `s` with the launch's number of waves
 inline CountWs workspace_count_ticket(c2d_ctx* ctx, hipStream_t s, size_t n_waves, bool counted)
 {
     CountWs ws{ctx->d_count_words, 0};
     if (!counted || stream_is_capturing(s)) return ws;
-    ws.ticket = ++ctx->ws_ticket;
+    ws.ticket = workspace_next_ticket(ctx);
     const size_t used = n_waves < kCountWords ? n_waves : kCountWords;
     for (size_t i = 0; i < used; i++) ctx->ws_expect[i] = ws.ticket;
     ctx->ws_stream = s;
@@ -170,7 +184,7 @@ inline CountWs workspace_count_ticket2(c2d_ctx* ctx, hipStream_t s, size_t n_wav
 {
     CountWs ws{ctx->d_count_words2, 0};
     if (!counted || stream_is_capturing(s)) return ws;
-    ws.ticket = ++ctx->ws_ticket;
+    ws.ticket = workspace_next_ticket(ctx);
     size_t used = n_waves < kCountWords1 ? n_waves : kCountWords1;
     used = used < kCountWords2 ? used : kCountWords2;
     for (size_t i = 0; i < used; i++) ctx->ws_expect[kCountWords + i] = ws.ticket;
