@@ -428,6 +428,17 @@ int c2d_dist_stream_synchronize(c2d_dist* d, c2d_stream stream)
 
 int c2d_dist_timed_out(const c2d_dist* d) { return d && d->timed_out ? 1 : 0; }
 
+#ifdef C2D_DIST_REHEARSAL
+// Test hook of the rehearsal build only (not in include/c2d.h, not in the product library): sets the workspace guard's ticket
+// counter, so that tests/test_gpu_workspace_guard.py can walk it through the 32-bit wrap that otherwise comes after 2^32 launches.
+int c2d_test_set_workspace_ticket(c2d_ctx* ctx, unsigned value)
+{
+    if (!ctx) return C2D_ERR_INVALID_ARG;
+    ctx->ws_ticket = value;
+    return C2D_OK;
+}
+#endif
+
 int c2d_dist_destroy(c2d_dist* d)
 {
     if (!d) return C2D_OK;
