@@ -1,6 +1,10 @@
 """Tests of the C++ host drivers (the reference's CLI surface).
 CPU part: flag parsing, .npy files readable by numpy, loud failure without a GPU.
-GPU part: end-to-end runs whose rows equal the CPU oracle's."""
+End-to-end runs whose rows equal the CPU oracle's come in two flavours of the same test: `[gpu]` = the shipped binaries on
+libc2d.so (`-m gpu`), `[double]` = the same driver sources compiled against tests/cpp/c2d_cpu_double.cpp, a TEST DOUBLE of the C-ABI
+that hands the Monte-Carlo work to the oracle — so that the drivers' host logic (tables and their files, batch numbering, scene-id
+bases, the deal of batches over ranks, shuffles, summaries) is exercised in the CPU suite too.  The double says nothing about the
+kernels; it is never built into, linked with or selectable by the product."""
 import json
 import os
 import subprocess
@@ -17,6 +21,33 @@ ZT = os.path.join(BIN, "ztest")
 
 def run(cmd, **kw):
     return subprocess.run(cmd, capture_output=True, text=True, timeout=600, **kw)
+
+
+@pytest.fixture(scope="session")
+def double_dir(tmp_path_factory):
+    """generate_dataset, compute_collision_probability and ztest compiled against the CPU test double"""
+    d = tmp_path_factory.mktemp("drivers_on_the_cpu_double")
+    host = os.path.join(ROOT, "convex-2d-gpu-collision-detection_amd", "csrc", "host")
+    oracle_dir = os.path.join(ROOT, "oracle")
+    procs = [subprocess.Popen(["g++", "-O1", "-std=c++17", "-pthread", "-Wall", "-Wextra", "-I" + os.path.join(ROOT, "include"), os.path.join(host, name + ".cpp"),
+                               os.path.join(ROOT, "tests", "cpp", "c2d_cpu_double.cpp"), "-o", str(d / name), "-L" + oracle_dir, "-lc2d_oracle",
+                               "-Wl,-rpath," + oracle_dir]) for name in ("generate_dataset", "compute_collision_probability", "ztest")]
+    assert all(p.wait() == 0 for p in procs)
+    return d
+
+
+@pytest.fixture(params=[pytest.param("gpu", marks=pytest.mark.gpu), "double"])
+def drv(request):
+    """the three drivers: the shipped binaries (needs the GPU) or the ones on the CPU double"""
+    import types
+
+    if request.param == "gpu":
+        return types.SimpleNamespace(kind="gpu", GEN=GEN, CCP=CCP, ZT=ZT, run=run)
+    d = request.getfixturevalue("double_dir")
+    request.getfixturevalue("oracle")   # (builds the oracle library if missing)
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    return types.SimpleNamespace(kind="double", GEN=str(d / "generate_dataset"), CCP=str(d / "compute_collision_probability"), ZT=str(d / "ztest"),
+                                 run=lambda cmd, **kw: run(cmd, env=dict(env, **kw.pop("env", {})), **kw))
 
 
 def test_help_lists_every_reference_flag():
@@ -76,10 +107,9 @@ def test_generate_dataset_fails_loudly_without_gpu(tmp_path):
     assert not (d / "poses.npy").exists() and not (d / "variances.npy").exists()
 
 
-@pytest.mark.gpu
-def test_generate_dataset_tables_and_meta_files(tmp_path):
+def test_generate_dataset_tables_and_meta_files(tmp_path, drv):
     d = tmp_path / "data"
-    out = run([GEN, "--data_dir", str(d), "-n", "1", "-b", "100", "--num_poses", "1000", "--num_variances", "500", "--max_samples", "2000",
+    out = drv.run([drv.GEN, "--data_dir", str(d), "-n", "1", "-b", "100", "--num_poses", "1000", "--num_variances", "500", "--max_samples", "2000",
                "--min_pose", "0.5", "0.25", "0", "--max_pose", "2", "3", "1", "--accuracy_bins", "0", "0.5", "1",
                "--bin_accuracy", "0.01", "0.02", "--seed", "1"])
     assert out.returncode == 0, out.stderr
@@ -134,11 +164,10 @@ def test_ccp_reads_numpy_written_inputs_then_fails_loudly_without_gpu(tmp_path):
 
 # ---- GPU end-to-end ---------------------------------------------------------------------------
 
-@pytest.mark.gpu
-def test_generate_dataset_end_to_end_matches_oracle(tmp_path, oracle):
+def test_generate_dataset_end_to_end_matches_oracle(tmp_path, oracle, drv):
     d = tmp_path / "data"
     B, NB = 1500, 2
-    out = run([GEN, "--data_dir", str(d), "-n", str(NB), "-b", str(B), "-s", "3", "--num_poses", "200", "--num_variances", "100",
+    out = drv.run([drv.GEN, "--data_dir", str(d), "-n", str(NB), "-b", str(B), "-s", "3", "--num_poses", "200", "--num_variances", "100",
                "--max_samples", "3000", "--seed", "77", "--shape_variance", "--spread", "3.5"])
     assert out.returncode == 0, out.stderr
     summary = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
@@ -165,8 +194,7 @@ def test_generate_dataset_end_to_end_matches_oracle(tmp_path, oracle):
     assert summary["cp_hist"] == np.histogram(allrows[:, 2], [0, 0.001, 0.01, 0.1, 1])[0].tolist()   # balance_datasets.py:49
 
 
-@pytest.mark.gpu
-def test_ccp_end_to_end_matches_oracle_and_continues_numbering(tmp_path, oracle, wl):
+def test_ccp_end_to_end_matches_oracle_and_continues_numbering(tmp_path, oracle, wl, drv):
     din, dout = tmp_path / "in", tmp_path / "out"
     (dout / "meta").mkdir(parents=True)
     din.mkdir()
@@ -187,7 +215,7 @@ def test_ccp_end_to_end_matches_oracle_and_continues_numbering(tmp_path, oracle,
         s[:, 3] = rng.integers(0, 50, N)
         np.save(din / f"{k}.npy", s)
         batches.append(s)
-    out = run([CCP, "--data_in", str(din), "--data_out", str(dout), "--max_samples", "4000", "--shuffle", "false", "--seed", "9"])
+    out = drv.run([drv.CCP, "--data_in", str(din), "--data_out", str(dout), "--max_samples", "4000", "--shuffle", "false", "--seed", "9"])
     assert out.returncode == 0, out.stderr
     sd_from_var = np.sqrt(var).astype(np.float32).view(oracle.STD_DT).reshape(-1)
     for k in range(2):
@@ -198,8 +226,7 @@ def test_ccp_end_to_end_matches_oracle_and_continues_numbering(tmp_path, oracle,
         assert np.array_equal(rows.view(np.uint32), ref_rows.view(np.uint32).reshape(N, 5))   # input order kept (--shuffle false)
 
 
-@pytest.mark.gpu
-def test_ztest_single_file_modes(tmp_path, oracle, wl):
+def test_ztest_single_file_modes(tmp_path, oracle, wl, drv):
     """ztest: explicit files, default meta written, constant 10000-sample schedule, --cps_only."""
     d = tmp_path / "data"
     d.mkdir()
@@ -218,14 +245,70 @@ def test_ztest_single_file_modes(tmp_path, oracle, wl):
     _, used, ref_rows, _ = oracle.mc_scenes(poses, sd_from_var, s.view(oracle.SCENE_DT).reshape(-1), 4.07, 1.74, [0, .01, .1, 1],
                                             [1e-4, 1e-3, 1e-2], 30000, 4, 0, schedule=(10000, 10000, 0))
     assert set(np.unique(used).tolist()) <= {10000, 20000, 30000} and len(np.unique(used)) > 1
-    out = run([ZT, "--data_dir", str(d), "--data_file_in", str(tmp_path / "in.npy"), "--data_file_out", str(tmp_path / "rows.npy"),
+    out = drv.run([drv.ZT, "--data_dir", str(d), "--data_file_in", str(tmp_path / "in.npy"), "--data_file_out", str(tmp_path / "rows.npy"),
                "--max_samples", "30000", "--shuffle", "false", "--seed", "4"])
     assert out.returncode == 0, out.stderr + out.stdout
     assert np.allclose(np.load(d / "meta" / "accuracy_bins.npy"), [0, 0.01, 0.1, 1])
     rows = np.load(tmp_path / "rows.npy")
     assert np.array_equal(rows.view(np.uint32), ref_rows.view(np.uint32).reshape(N, 5))
-    out = run([ZT, "--data_dir", str(d), "--data_file_in", str(tmp_path / "in.npy"), "--data_file_out", str(tmp_path / "cps.npy"),
+    out = drv.run([drv.ZT, "--data_dir", str(d), "--data_file_in", str(tmp_path / "in.npy"), "--data_file_out", str(tmp_path / "cps.npy"),
                "--max_samples", "30000", "--shuffle", "false", "--seed", "4", "--cps_only", "true", "--meta_dir", str(d / "meta")])
     assert out.returncode == 0, out.stderr + out.stdout
     cps = np.load(tmp_path / "cps.npy")
     assert cps.shape == (N,) and np.array_equal(cps.view(np.uint32), ref_rows["cp"].view(np.uint32))
+
+
+def test_ranks_deal_batches_like_one_rank_on_the_double(tmp_path, wl, double_dir, oracle):
+    """The N > 1 host logic of both drivers on the CPU double (the GPU flavour of this test, with the rehearsal build of the
+    library, is tests/test_gpu_dist.py): `--gpus 2` and `--gpus 3` write the very batch files one rank writes, one summary
+    aggregated over the ranks, the reference's numbering continued; config 3 split by sample index sums to the one-rank count."""
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    gen, ccp = str(double_dir / "generate_dataset"), str(double_dir / "compute_collision_probability")
+    summary = lambda out: json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])  # noqa: E731
+    common = ["-n", "5", "-b", "400", "-s", "2", "--num_poses", "60", "--num_variances", "40", "--max_samples", "3000", "--seed", "11"]
+    outs = {}
+    for w in (1, 2, 3):
+        d = tmp_path / f"gen{w}"
+        o = run([gen, "--data_dir", str(d)] + common + (["--gpus", str(w)] if w > 1 else []), env=env)
+        assert o.returncode == 0, o.stderr + o.stdout
+        outs[w] = (d, summary(o))
+        assert [ln for ln in o.stdout.splitlines() if ln.startswith("{")].__len__() == 1          # one summary, rank 0's
+    d1, s1 = outs[1]
+    for w in (2, 3):
+        d, s = outs[w]
+        assert s["aggregated_over_ranks"] == w and s["world_size"] == w
+        for key in ("batches", "scenes", "mc_samples", "hits", "cp_hist"):
+            assert s[key] == s1[key], key
+        assert sorted(p.name for p in d.glob("[0-9]*.npy")) == [f"{k}.npy" for k in range(2, 7)]
+        for k in range(2, 7):
+            assert np.array_equal(np.load(d1 / f"{k}.npy").view(np.uint32), np.load(d / f"{k}.npy").view(np.uint32)), (w, k)
+        assert np.array_equal(np.load(d1 / "poses.npy"), np.load(d / "poses.npy"))
+    # compute_collision_probability on generate_dataset's own scenes, with an existing batch in the output directory
+    din = tmp_path / "in"
+    din.mkdir()
+    for k in range(2, 7):
+        a = np.load(d1 / f"{k}.npy")
+        np.save(din / f"{k - 2}.npy", np.ascontiguousarray(a[:, [0, 1, 3, 4]]))
+    res = {}
+    for w in (1, 3):
+        dout = tmp_path / f"ccp{w}"
+        (dout / "meta").mkdir(parents=True)
+        for f in ("poses.npy", "variances.npy"):
+            np.save(dout / f, np.load(d1 / f))
+        for f in ("accuracy_bins.npy", "bin_accuracy.npy"):
+            np.save(dout / "meta" / f, np.load(d1 / "meta" / f))
+        np.save(dout / "0.npy", np.zeros((3, 5), np.float32))
+        o = run([ccp, "--data_in", str(din), "--data_out", str(dout), "--max_samples", "3000", "--seed", "4"] + (["--gpus", str(w)] if w > 1 else []), env=env)
+        assert o.returncode == 0, o.stderr + o.stdout
+        res[w] = (dout, summary(o))
+    for k in range(1, 6):
+        assert np.array_equal(np.load(res[1][0] / f"{k}.npy").view(np.uint32), np.load(res[3][0] / f"{k}.npy").view(np.uint32)), k
+    assert res[3][1]["aggregated_over_ranks"] == 3 and res[3][1]["mc_samples"] == res[1][1]["mc_samples"] and res[3][1]["hits"] == res[1][1]["hits"]
+    sc = wl.MC_PAIR_SCENE
+    S = 300_001
+    ref = oracle.mc_pair(sc["robot_w"], sc["robot_h"], sc["pos"], sc["pose"], sc["std_dev"], 1234, 0, 0, S)
+    for w in (1, 4):
+        o = run([ccp, "--pair_samples", str(S), "--seed", "1234"] + (["--gpus", str(w)] if w > 1 else []), env=env)
+        assert o.returncode == 0, o.stderr
+        s = summary(o)
+        assert s["hits"] == ref and s["samples"] == S and s["aggregated_over_ranks"] == w

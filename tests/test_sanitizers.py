@@ -59,3 +59,53 @@ def test_watchdog_under_tsan(tmp_path):
     subprocess.run([cxx, "-std=c++17", "-fsanitize=thread", "-g", "-O1", "-pthread", "-DWATCHDOG_TEST_PLANT_RACE", inc, src, "-o", str(racy)], check=True)
     out = subprocess.run([str(racy)], capture_output=True, text=True, env=env, timeout=300)
     assert "ThreadSanitizer: data race" in out.stderr or "ThreadSanitizer: heap-use-after-free" in out.stderr, out.stdout + out.stderr
+
+
+def _driver_on_the_double(cxx, flags, name, out):
+    host = os.path.join(ROOT, "convex-2d-gpu-collision-detection_amd", "csrc", "host")
+    oracle_dir = os.path.join(ROOT, "oracle")
+    subprocess.run([cxx, "-std=c++17", "-pthread"] + flags + ["-I" + os.path.join(ROOT, "include"), os.path.join(host, name + ".cpp"),
+                    os.path.join(ROOT, "tests", "cpp", "c2d_cpu_double.cpp"), "-o", str(out), "-L" + oracle_dir, "-lc2d_oracle", "-Wl,-rpath," + oracle_dir], check=True)
+
+
+def test_drivers_under_asan_ubsan_on_the_cpu_double(tmp_path):
+    """generate_dataset (its own launcher with three ranks, the saver thread, two batches in flight, the RAII holders on the way out)
+    and compute_collision_probability on its output, compiled with AddressSanitizer + UndefinedBehaviourSanitizer against the CPU
+    test double of the C-ABI (tests/cpp/c2d_cpu_double.cpp); and an error path: a missing input directory must leave through the
+    holders without a leak report."""
+    import numpy as np
+
+    gen, ccp = tmp_path / "gen_san", tmp_path / "ccp_san"
+    _driver_on_the_double("g++", SAN, "generate_dataset", gen)
+    _driver_on_the_double("g++", SAN, "compute_collision_probability", ccp)
+    env = dict(ENV, OMP_NUM_THREADS="1", ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:verify_asan_link_order=0")
+    d = tmp_path / "data"
+    out = subprocess.run([str(gen), "--data_dir", str(d), "-n", "4", "-b", "200", "--num_poses", "50", "--num_variances", "30", "--max_samples", "2000", "--seed", "3",
+                          "--gpus", "3"], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr and "LeakSanitizer" not in out.stderr, out.stderr
+    assert sorted(p.name for p in d.glob("[0-9]*.npy")) == ["0.npy", "1.npy", "2.npy", "3.npy"]
+    din = tmp_path / "in"
+    din.mkdir()
+    np.save(din / "0.npy", np.ascontiguousarray(np.load(d / "0.npy")[:, [0, 1, 3, 4]]))
+    out = subprocess.run([str(ccp), "--data_in", str(din), "--data_out", str(d), "--max_samples", "2000", "--seed", "3"], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0 and (d / "4.npy").exists(), out.stdout + out.stderr
+    assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr and "LeakSanitizer" not in out.stderr, out.stderr
+    # an error after the device was opened: a device index the double does not have -> C2D_CALL returns from main()
+    out = subprocess.run([str(ccp), "--data_in", str(din), "--data_out", str(d), "--device", "99"], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode != 0 and "no usable device" in out.stderr
+    assert "AddressSanitizer" not in out.stderr and "LeakSanitizer" not in out.stderr, out.stderr
+
+
+def test_generate_dataset_under_tsan_on_the_cpu_double(tmp_path):
+    """The driver's own threads — the table saver beside the batch loop — under ThreadSanitizer (the oracle runs single-threaded:
+    libgomp is not instrumented)."""
+    cxx = _tsan_compiler()
+    assert cxx, "no clang++ for the ThreadSanitizer build"
+    gen = tmp_path / "gen_tsan"
+    _driver_on_the_double(cxx, ["-fsanitize=thread", "-g", "-O1"], "generate_dataset", gen)
+    env = dict(os.environ, OMP_NUM_THREADS="1", TSAN_OPTIONS="halt_on_error=0:report_thread_leaks=0")
+    out = subprocess.run([str(gen), "--data_dir", str(tmp_path / "data"), "-n", "4", "-b", "200", "--num_poses", "50", "--num_variances", "30", "--max_samples", "2000",
+                          "--seed", "3"], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ThreadSanitizer" not in out.stderr, out.stderr
