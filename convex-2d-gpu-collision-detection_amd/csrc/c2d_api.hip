@@ -111,7 +111,8 @@ int c2d_ctx_info(const c2d_ctx* ctx, c2d_device_info* out)
     if (!ctx || !out) return C2D_ERR_INVALID_ARG;
     std::memset(out, 0, sizeof *out);
     // (some boxes of the pool report an empty marketing name: the architecture then stands in for it)
-    std::snprintf(out->name, sizeof out->name, "%s", ctx->prop.name[0] ? ctx->prop.name : ctx->prop.gcnArchName);
+    if (ctx->prop.name[0]) std::snprintf(out->name, sizeof out->name, "%s", ctx->prop.name);
+    else std::snprintf(out->name, sizeof out->name, "gfx950 device (the runtime reports no marketing name)");
     std::snprintf(out->arch, sizeof out->arch, "%s", ctx->prop.gcnArchName);
     out->device = ctx->device;
     out->compute_units = ctx->prop.multiProcessorCount;
