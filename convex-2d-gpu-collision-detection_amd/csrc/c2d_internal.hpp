@@ -207,7 +207,13 @@ struct WorkspaceUse {
     WorkspaceUse(const WorkspaceUse&) = delete;
     WorkspaceUse& operator=(const WorkspaceUse&) = delete;
     void arm() { armed = true; }
-    ~WorkspaceUse() { if (armed) workspace_stamp_behind(ctx, s); }
+    // everything is queued: stamp now (a caller that goes on to synchronise the stream then finds the guard's tickets retired)
+    void done()
+    {
+        if (armed) workspace_stamp_behind(ctx, s);
+        armed = false;
+    }
+    ~WorkspaceUse() { done(); }
 };
 
 // `s` has been synchronised by the caller: if it is the stream the outstanding tickets were issued on, they have retired.

@@ -639,9 +639,11 @@ int run_adaptive(c2d_ctx* ctx, const c2d_mc_scenes_args* a, c2d_stream stream, A
         }
     }
     C2D_LAUNCH_CHECK(ctx);
+    use.done();      // the guard's stamp goes behind the schedule, in front of the read-back
     if (host_out) {  // host outputs requested: one read-back at the end
         C2D_HIP(ctx, hipMemcpyAsync(h_state, d_state, sizeof(AdaptiveState), hipMemcpyDeviceToHost, s));
         C2D_HIP(ctx, hipStreamSynchronize(s));
+        workspace_stream_drained(ctx, s);
         if (a->total_samples) *a->total_samples = h_state->total_samples;
         if (a->iterations) *a->iterations = h_state->iter;
     }
