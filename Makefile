@@ -11,7 +11,7 @@ SRCS := $(CSRC)/c2d_api.hip $(CSRC)/c2d_host.hip $(CSRC)/c2d_sat.hip $(CSRC)/c2d
 OBJS := $(SRCS:.hip=.o)
 HDRS := $(CSRC)/c2d_math.hpp $(CSRC)/c2d_mc_core.hpp $(CSRC)/c2d_count.hpp $(CSRC)/c2d_internal.hpp include/c2d.h include/utils.h
 
-all: lib oracle drivers lib-fmad lib-nopretest lib-rehearsal
+all: lib oracle drivers lib-fmad lib-nopretest lib-rehearsal lib-movecheck
 
 lib: $(LIBDIR)/libc2d.so
 
@@ -38,7 +38,7 @@ clean:
 	rm -f $(OBJS) $(LIBDIR)/libc2d.so $(BINDIR)/generate_dataset $(BINDIR)/compute_collision_probability $(BINDIR)/ztest
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle drivers tools clean lib-fmad lib-nopretest lib-rehearsal lib-mcstats lib-mcclock lib-ab-stamps
+.PHONY: all lib oracle drivers tools clean lib-fmad lib-nopretest lib-rehearsal lib-mcstats lib-mcclock lib-ab-stamps lib-movecheck
 
 # developer tools (not shipped in libc2d.so)
 TOOLS := $(CSRC)/tools/sat_tune $(CSRC)/tools/pose_probe $(CSRC)/tools/clock_probe $(CSRC)/tools/instr_probe $(CSRC)/tools/store_pattern_probe $(CSRC)/tools/stream_lifetime_probe
@@ -73,6 +73,15 @@ $(CSRC)/c2d_dist_rehearsal.o: $(CSRC)/c2d_dist.hip $(HDRS)
 $(REHDIR)/libc2d.so: $(OBJS) $(CSRC)/c2d_dist_rehearsal.o
 	@mkdir -p $(REHDIR)
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(filter-out $(CSRC)/c2d_dist.o,$(OBJS)) $(CSRC)/c2d_dist_rehearsal.o -ldl
+
+# developer build: the binning pass's move kernel checks every index against its array and reports the first offender on
+# stderr instead of making the access (C2D_MOVE_CHECK in c2d_poly_binned.hip); run anything on it with C2D_LIBRARY=...
+lib-movecheck: $(LIBDIR)/libc2d_movecheck.so
+$(CSRC)/c2d_poly_binned_movecheck.o: $(CSRC)/c2d_poly_binned.hip $(HDRS)
+	$(HIPCC) $(HIPFLAGS) -DC2D_MOVE_CHECK -c $< -o $@
+$(LIBDIR)/libc2d_movecheck.so: $(OBJS) $(CSRC)/c2d_poly_binned_movecheck.o
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(filter-out $(CSRC)/c2d_poly_binned.o,$(OBJS)) $(CSRC)/c2d_poly_binned_movecheck.o -ldl
 
 # census build (developer tool, not part of `all`): Monte-Carlo kernels that count where their samples go (C2D_MC_STATS in c2d_mc.hip);
 # tests/tools/mc_stats.py reads the counters and records the evaluated-sample fraction the bench quotes

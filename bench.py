@@ -193,44 +193,13 @@ def torch_random_convex_polygons(torch, dev, n, seed, kmin=3, kmax=KMAX, extent=
     return vx, vy, k.to(torch.uint8)
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--pairs", type=int, default=10_000_000, help="rectangle pairs per GPU (config 2: 1e7)")
-    ap.add_argument("--mc-samples", type=int, default=100_000_000, help="MC samples per GPU (config 3: 1e8)")
-    ap.add_argument("--mc-reps", type=int, default=20)
-    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target wall time of the CPU baseline leg")
-    ap.add_argument("--prewarm-ms", type=float, default=150.0,
-                    help="untimed device wake-up before the W warm-up steps: the first ~15 ms of load after idle run "
-                         "up to 12 %% slower while the power manager ramps clocks (profiles/r01a trace)")
-    ap.add_argument("--poly-scenes", type=int, default=200_000, help="scenes per GPU of the adaptive polygon Monte-Carlo sub-leg (0 = skip)")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="torch.distributed backend for rendezvous / barriers; nccl (= RCCL over xGMI) is the measured path, gloo only "
-                         "rehearses the N > 1 code path on a box with fewer GPUs than ranks (together with --share-device; the "
-                         "c2d reduce then uses its file rehearsal transport, since RCCL refuses two ranks on one device)")
-    ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses GPU 0")
-    ap.add_argument("--force-dist", action="store_true",
-                    help="rehearsal: initialise the process group and run the collectives even with one rank")
-    ap.add_argument("--reduce", default="c2d", choices=["c2d", "torch"],
-                    help="who sums the hit counters over ranks: libc2d's c2d_dist (RCCL, default) or torch.distributed")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-mc", action="store_true")
-    ap.add_argument("--no-pose", action="store_true")
-    ap.add_argument("--scenes", type=int, default=4_000_000,
-                    help="config 4 data points per GPU (1e6 scenes x 32 obstacle instances / 8 GPUs); 0 = skip the leg")
-    ap.add_argument("--scenes-max-samples", type=int, default=120_000)
-    ap.add_argument("--poly-pairs", type=int, default=10_000_000, help="config 5 polygon pairs per GPU; 0 = skip the leg")
-    ap.add_argument("--poly-reps", type=int, default=20)
-    ap.add_argument("--poly-bin-granularity", type=int, default=1,
-                    help="binned polygon leg: polygon sizes rounded up to this many rows per bin (1 = one bin per (ka, kb): the exact bytes)")
-    args = ap.parse_args()
+class Run:
+    """What the legs of one bench run share: setup() puts the rank, the device, the engine, the stream and the reduce on it, every leg reads what it
+    needs from it at its top and leaves what later legs and the result line read at its bottom (the data flow between the legs is those lines)."""
 
-    launched = "WORLD_SIZE" in os.environ or "RANK" in os.environ
-    if args.gpus > 1 and not launched:
-        sys.exit(self_launch(args.gpus))  # nothing GPU-related has been imported yet
 
+def setup(args, R) -> None:
+    """rank, device, engine, stream, the reduce (torch.distributed + libc2d's communicator) and the helpers every leg uses, onto R"""
     # Exactly one line may reach stdout (the JSON result).  Libraries write there too — RCCL prints a
     # version banner to stdout when its communicator is created — so fd 1 is pointed at stderr for the
     # whole run and the result is written to the saved descriptor at the end.
@@ -348,7 +317,17 @@ def main() -> None:
         torch.cuda.synchronize()  # (two communicators live in this process — c2d's and torch's: never a collective of each in flight at once)
         dist.barrier()
         torch.cuda.synchronize()
+    # what the later legs and the result line read
+    R.all_reduce_sum, R.args, R.cdist, R.counts, R.dev, R.dev_info, R.dist, R.eng, R.pkg, R.rank = all_reduce_sum, args, cdist, counts, dev, dev_info, dist, eng, pkg, rank
+    R.rccl_library, R.rccl_version, R.real_stdout, R.reduce_impl, R.sh, R.shd, R.stream, R.torch, R.use_dist, R.wl = rccl_library, rccl_version, real_stdout, reduce_impl, sh, shd, stream, torch, use_dist, wl
+    R.world, = world,
 
+
+def leg_pairs(R) -> None:
+    """workload: config 2, resident in HBM"""
+    # state the legs before this one left on R
+    all_reduce_sum, args, counts, dev, dist, eng, rank, sh, shd, stream = R.all_reduce_sum, R.args, R.counts, R.dev, R.dist, R.eng, R.rank, R.sh, R.shd, R.stream
+    torch, use_dist, world = R.torch, R.use_dist, R.world
     # ---- workload: config 2, resident in HBM -----------------------------------------
     n = args.pairs
     gen = torch.Generator(device=dev)
@@ -436,7 +415,15 @@ def main() -> None:
                 "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": BYTES_PER_PAIR * n, "kernel_ms": round(kernel_ms, 5),
                 "step_ms_distribution": step_ms}
+    # what the later legs and the result line read
+    R.barrier, R.collide_rate, R.count_after_timed, R.elapsed, R.n, R.out, R.plane_ptrs, R.planes, R.pose, R.pose_ptrs = barrier, collide_rate, count_after_timed, elapsed, n, out, plane_ptrs, planes, pose, pose_ptrs
+    R.prewarm, R.roofline, R.step_distribution, R.value = prewarm, roofline, step_distribution, value
 
+
+def leg_mask_output(R) -> None:
+    """same kernel arithmetic, bit-mask output (64.125 B/pair)"""
+    # state the legs before this one left on R
+    args, counts, dev, eng, n, plane_ptrs, prewarm, sh, stream, torch = R.args, R.counts, R.dev, R.eng, R.n, R.plane_ptrs, R.prewarm, R.sh, R.stream, R.torch
     # ---- same kernel arithmetic, bit-mask output (64.125 B/pair) ---------------------------------------------------
     mask_leg = None
     if not args.no_pose:
@@ -465,7 +452,15 @@ def main() -> None:
             mask_leg["roofline"]["traffic"] = c.get("hbm_bytes_per_launch")
             mask_leg["roofline"]["traffic_source"] = "recorded, not measured in this run: %s" % c.get("source")
         del mwords
+    # what the later legs and the result line read
+    R.mask_leg, = mask_leg,
 
+
+def leg_pose_format(R) -> None:
+    """secondary input format: poses (41 B/pair), reported separately"""
+    # state the legs before this one left on R
+    args, counts, dev, eng, n, out, pose_ptrs, prewarm, sh, step_distribution = R.args, R.counts, R.dev, R.eng, R.n, R.out, R.pose_ptrs, R.prewarm, R.sh, R.step_distribution
+    stream, torch = R.stream, R.torch
     # ---- secondary input format: poses (41 B/pair), reported separately (SURVEY.md §8d) ----------
     pose_leg = None
     if not args.no_pose:
@@ -502,6 +497,14 @@ def main() -> None:
                                                  "pair test (round 3) took the kernel from 294 to the recorded instruction count per pair"}
             pose_leg["roofline"]["traffic"] = c.get("hbm_bytes_per_launch")
             pose_leg["roofline"]["traffic_source"] = "recorded, not measured in this run: %s" % c.get("source")
+    # what the later legs and the result line read
+    R.pose_leg, = pose_leg,
+
+
+def leg_host_resident(R) -> None:
+    """the same batch starting in HOST memory (include/c2d.h c2d_sat_rect_pairs_*_host): never `value` — the link is the bound"""
+    # state the legs before this one left on R
+    args, eng, n, out, planes, pose, rank, world = R.args, R.eng, R.n, R.out, R.planes, R.pose, R.rank, R.world
     # ---- the same batch starting in HOST memory (include/c2d.h c2d_sat_rect_pairs_*_host): never `value` — the link is the bound ---
     host_leg = None
     if not args.no_pose and rank == 0 and world == 1:
@@ -548,7 +551,16 @@ def main() -> None:
         for a_ in (pin, pin_pose, h_res):
             eng.host_free(a_)
     del pose
+    # what the later legs and the result line read
+    R.host_leg, R.pose = host_leg, None
 
+
+def leg_mc(R) -> None:
+    """Monte-Carlo leg: config 3"""
+    # state the legs before this one left on R
+    all_reduce_sum, args, barrier, counts, dev, eng, prewarm, rank, sh, shd = R.all_reduce_sum, R.args, R.barrier, R.counts, R.dev, R.eng, R.prewarm, R.rank, R.sh, R.shd
+    stream, torch, wl, world = R.stream, R.torch, R.wl, R.world
+    S = mc_hits_one_step = sc = None
     # ---- Monte-Carlo leg: config 3 --------------------------------------------------------
     mc = None
     if not args.no_mc:
@@ -596,7 +608,16 @@ def main() -> None:
                               "instr_source": c.get("source")}
             held_clock(mc["roofline"], c)
             issue_weighted(mc["roofline"], c, S / (mc_kernel_ms * 1e-3) * c["valu_instr_per_sample"] / 64)
+    # what the later legs and the result line read
+    R.S, R.mc, R.mc_hits_one_step, R.sc = S, mc, mc_hits_one_step, sc
 
+
+def leg_mc_poly(R) -> None:
+    """Monte-Carlo over convex polygons (README.md:3 "arbitrary convex 2D shapes"; include/c2d.h c2d_mc_poly_pair)"""
+    # state the legs before this one left on R
+    all_reduce_sum, args, barrier, counts, dev, eng, pkg, prewarm, rank, sh = R.all_reduce_sum, R.args, R.barrier, R.counts, R.dev, R.eng, R.pkg, R.prewarm, R.rank, R.sh
+    shd, stream, torch, wl, world = R.shd, R.stream, R.torch, R.wl, R.world
+    PS = mc_poly_hits_one_step = mc_poly_scenes_keep = psc = None
     # ---- Monte-Carlo over convex polygons (README.md:3 "arbitrary convex 2D shapes"; include/c2d.h c2d_mc_poly_pair) -------------
     mc_poly = None
     if not args.no_mc:
@@ -677,7 +698,15 @@ def main() -> None:
             mc_poly_scenes_keep = (pp_tab, ps_tab, p_scn, p_rob9, d_ph.get(), d_pu.get(), rank * PN)
             for a_ in (d_pp, d_ps, d_pscn, d_ph, d_pu):
                 a_.free()
+    # what the later legs and the result line read
+    R.PS, R.mc_poly, R.mc_poly_hits_one_step, R.mc_poly_scenes_keep, R.psc = PS, mc_poly, mc_poly_hits_one_step, mc_poly_scenes_keep, psc
 
+
+def leg_scenes(R) -> None:
+    """config 4: adaptive Monte-Carlo over many scenes"""
+    # state the legs before this one left on R
+    all_reduce_sum, args, barrier, counts, dev, eng, pkg, rank, sh, shd = R.all_reduce_sum, R.args, R.barrier, R.counts, R.dev, R.eng, R.pkg, R.rank, R.sh, R.shd
+    stream, torch, wl, world = R.stream, R.torch, R.wl, R.world
     # ---- config 4: adaptive Monte-Carlo over many scenes -------------------------------------
     scenes_leg, scenes_keep = None, None
     if args.scenes > 0:
@@ -771,7 +800,15 @@ def main() -> None:
         for a_ in (d_p, d_s, d_sc):
             a_.free()
         del t_h, t_u
+    # what the later legs and the result line read
+    R.scenes_keep, R.scenes_leg = scenes_keep, scenes_leg
 
+
+def leg_poly(R) -> None:
+    """config 5: convex polygons K <= 16"""
+    # state the legs before this one left on R
+    all_reduce_sum, args, barrier, counts, dev, eng, prewarm, rank, sh, shd = R.all_reduce_sum, R.args, R.barrier, R.counts, R.dev, R.eng, R.prewarm, R.rank, R.sh, R.shd
+    step_distribution, stream, torch, world = R.step_distribution, R.stream, R.torch, R.world
     # ---- config 5: convex polygons K <= 16 ---------------------------------------------------------
     poly_leg, poly_keep = None, None
     if args.poly_pairs > 0:
@@ -917,7 +954,16 @@ def main() -> None:
             poly_leg["small_polygons"]["roofline"]["traffic"] = c4["hbm_bytes_per_launch"]
             poly_leg["small_polygons"]["roofline"]["traffic_source"] = "recorded, not measured in this run: %s" % c4.get("source")
         del vx4, vy4, kk4, pout
+    # what the later legs and the result line read
+    R.poly_keep, R.poly_leg = poly_keep, poly_leg
 
+
+def cpu_baselines_and_parity(R) -> None:
+    """CPU baseline + full-size parity: oracle port on this host, rank 0, N = 1 only"""
+    # state the legs before this one left on R
+    PS, S, args, count_after_timed, mc, mc_hits_one_step, mc_poly, mc_poly_hits_one_step, mc_poly_scenes_keep, n = R.PS, R.S, R.args, R.count_after_timed, R.mc, R.mc_hits_one_step, R.mc_poly, R.mc_poly_hits_one_step, R.mc_poly_scenes_keep, R.n
+    out, planes, poly_keep, poly_leg, psc, rank, sc, scenes_keep, scenes_leg, wl = R.out, R.planes, R.poly_keep, R.poly_leg, R.psc, R.rank, R.sc, R.scenes_keep, R.scenes_leg, R.wl
+    world, = R.world,
     # ---- CPU baseline + full-size parity: oracle port on this host, rank 0, N = 1 only ------------------------------
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -1047,7 +1093,15 @@ def main() -> None:
                 if fbad:
                     raise SystemExit("PARITY FAILURE: fixed-samples Monte-Carlo hits differ from the CPU oracle")
             scenes_keep = None
+    # what the later legs and the result line read
+    R.cpu_baseline, = cpu_baseline,
 
+
+def emit(R) -> None:
+    # state the legs before this one left on R
+    args, cdist, collide_rate, cpu_baseline, dev_info, dist, elapsed, eng, host_leg, mask_leg = R.args, R.cdist, R.collide_rate, R.cpu_baseline, R.dev_info, R.dist, R.elapsed, R.eng, R.host_leg, R.mask_leg
+    mc, mc_poly, n, poly_leg, pose_leg, rank, rccl_library, rccl_version, real_stdout, reduce_impl = R.mc, R.mc_poly, R.n, R.poly_leg, R.pose_leg, R.rank, R.rccl_library, R.rccl_version, R.real_stdout, R.reduce_impl
+    roofline, scenes_leg, use_dist, value, world = R.roofline, R.scenes_leg, R.use_dist, R.value, R.world
     if rank == 0:
         line = {
             "metric": "sat_pair_tests_per_s", "value": value, "unit": "pair_tests/s", "n_gpus": world, "steps": args.steps,
@@ -1071,6 +1125,50 @@ def main() -> None:
     if use_dist:
         dist.destroy_process_group()
 
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--pairs", type=int, default=10_000_000, help="rectangle pairs per GPU (config 2: 1e7)")
+    ap.add_argument("--mc-samples", type=int, default=100_000_000, help="MC samples per GPU (config 3: 1e8)")
+    ap.add_argument("--mc-reps", type=int, default=20)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target wall time of the CPU baseline leg")
+    ap.add_argument("--prewarm-ms", type=float, default=150.0,
+                    help="untimed device wake-up before the W warm-up steps: the first ~15 ms of load after idle run "
+                         "up to 12 %% slower while the power manager ramps clocks (profiles/r01a trace)")
+    ap.add_argument("--poly-scenes", type=int, default=200_000, help="scenes per GPU of the adaptive polygon Monte-Carlo sub-leg (0 = skip)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for rendezvous / barriers; nccl (= RCCL over xGMI) is the measured path, gloo only "
+                         "rehearses the N > 1 code path on a box with fewer GPUs than ranks (together with --share-device; the "
+                         "c2d reduce then uses its file rehearsal transport, since RCCL refuses two ranks on one device)")
+    ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: initialise the process group and run the collectives even with one rank")
+    ap.add_argument("--reduce", default="c2d", choices=["c2d", "torch"],
+                    help="who sums the hit counters over ranks: libc2d's c2d_dist (RCCL, default) or torch.distributed")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mc", action="store_true")
+    ap.add_argument("--no-pose", action="store_true")
+    ap.add_argument("--scenes", type=int, default=4_000_000,
+                    help="config 4 data points per GPU (1e6 scenes x 32 obstacle instances / 8 GPUs); 0 = skip the leg")
+    ap.add_argument("--scenes-max-samples", type=int, default=120_000)
+    ap.add_argument("--poly-pairs", type=int, default=10_000_000, help="config 5 polygon pairs per GPU; 0 = skip the leg")
+    ap.add_argument("--poly-reps", type=int, default=20)
+    ap.add_argument("--poly-bin-granularity", type=int, default=1,
+                    help="binned polygon leg: polygon sizes rounded up to this many rows per bin (1 = one bin per (ka, kb): the exact bytes)")
+    args = ap.parse_args()
+
+    launched = "WORLD_SIZE" in os.environ or "RANK" in os.environ
+    if args.gpus > 1 and not launched:
+        sys.exit(self_launch(args.gpus))  # nothing GPU-related has been imported yet
+
+    R = Run()
+    setup(args, R)
+    for leg in (leg_pairs, leg_mask_output, leg_pose_format, leg_host_resident, leg_mc, leg_mc_poly, leg_scenes, leg_poly, cpu_baselines_and_parity, emit):
+        leg(R)
+
 
 if __name__ == "__main__":
     main()
+

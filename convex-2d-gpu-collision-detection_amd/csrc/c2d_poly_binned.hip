@@ -478,7 +478,22 @@ struct BinMoveArgs {
     uint32_t tiles_per_xcd;        // ceil(n_tiles / 8): block b takes tile (b % 8) * tiles_per_xcd + b / 8
     uint32_t* index;               // [n] out: position of input pair i; 0xffffffff = bad counts
     float* base;                   // the block every plane of every bin lives in: a plane position is an element offset from here
+#ifdef C2D_MOVE_CHECK  // (developer build: every index of the move kernel is checked against its array; the first offender is recorded and skipped)
+    unsigned long long lim_in, lim_k, lim_block, lim_prefix, lim_bins;
+    unsigned long long* chk;  // [0] = kind (0 none), [1] = index, [2] = limit, [3] = tile << 32 | thread
+#endif
 };
+#ifdef C2D_MOVE_CHECK
+#define C2D_MOVE_OK(kind, idx, lim) move_check(A.chk, kind, (unsigned long long)(idx), (unsigned long long)(lim), tile, t)
+C2D_DEV bool move_check(unsigned long long* chk, unsigned kind, unsigned long long idx, unsigned long long lim, uint32_t tile, uint32_t t)
+{
+    if (idx < lim) return true;
+    if (atomicCAS(&chk[0], 0ull, (unsigned long long)kind) == 0ull) { chk[1] = idx; chk[2] = lim; chk[3] = ((unsigned long long)tile << 32) | t; }
+    return false;
+}
+#else
+#define C2D_MOVE_OK(kind, idx, lim) true
+#endif
 
 // The move: a block owns a TILE of 8192 consecutive pairs (kMoveTile).  Lanes that write one pair each scatter 4-byte stores over as many
 // cache lines as there are classes in a wave (196 bins: 7.5 ms per 1e7 pairs), so the tile is first sorted by destination:
@@ -562,7 +577,7 @@ __global__ __launch_bounds__(kBinBlock, (kMoveTile <= 4096 ? 2 : 1) * kBinWaves 
         const uint32_t c = t;
         const uint32_t bin = A.class_to_bin[c];
         uint32_t cnt = 0, first = 0;
-        if (bin != 0xffffu) {
+        if (bin != 0xffffu && C2D_MOVE_OK(1, bin, A.lim_bins) && C2D_MOVE_OK(2, (size_t)tile * 256 + c + (tile + 1 < A.n_tiles ? 256 : 0), A.lim_prefix)) {
             const BinDesc D = A.table[bin];
             s_plane[0][c] = (Off)(D.ax - A.base); s_plane[1][c] = (Off)(D.ay - A.base);
             s_plane[2][c] = (Off)(D.bx - A.base); s_plane[3][c] = (Off)(D.by - A.base);
@@ -602,7 +617,7 @@ __global__ __launch_bounds__(kBinBlock, (kMoveTile <= 4096 ? 2 : 1) * kBinWaves 
         const bool in = i < A.n;
         int ka = 0, kb = 0;
         uint32_t c = 0xffffffffu;
-        if (in) {
+        if (in && C2D_MOVE_OK(3, A.n + i, A.lim_k)) {
             ka = A.k[i];
             kb = A.k[A.n + i];
             c = bin_class(ka, kb, A.rows, A.g);
@@ -631,8 +646,9 @@ __global__ __launch_bounds__(kBinBlock, (kMoveTile <= 4096 ? 2 : 1) * kBinWaves 
                 const uint32_t in_tile = (uint32_t)s_wpre[wave][c] + rank;  // pairs of the class earlier in the tile
                 const uint32_t slot = s_first[c] + in_tile;
                 s_slot[li] = slot;
-                s_sorted[s_cbase[c] + in_tile] = (uint16_t)li;
+                if (C2D_MOVE_OK(4, s_cbase[c] + in_tile, kMoveTile)) s_sorted[s_cbase[c] + in_tile] = (uint16_t)li;
                 const uint32_t bin = A.class_to_bin[c];
+                (void)C2D_MOVE_OK(5, bin, A.lim_bins);
                 pos = A.pair_base[bin] + slot;
                 const BinDesc D = A.table[bin];
                 if (D.ka) {  // (two bytes per pair: written by the pair's own lane)
@@ -645,7 +661,13 @@ __global__ __launch_bounds__(kBinBlock, (kMoveTile <= 4096 ? 2 : 1) * kBinWaves 
     }
     __syncthreads();
     const uint32_t n_valid = s_cbase[256];
-    const uint32_t here = (uint32_t)((A.n - tile0) < (size_t)kMoveTile ? (A.n - tile0) : (size_t)kMoveTile);
+    // pairs of this tile.  In 32 bits on purpose (n < 2^32 - 64, checked by the host): written as a 64-bit compare and select, hipcc 7.2
+    // compiled the partial-tile path below with here = kMoveTile — v_cmp_lt_u64 into vcc, s_cbranch_vccz, then an s_cselect_b32 on an
+    // SCC that an unrelated s_add_i32 had set — so the last tile's loads were not guarded and ran up to 8191 floats past the end of
+    // vx / vy (read into registers nobody uses: results unaffected, but a fault when the batch ends at the end of a mapping;
+    // profiles/notes_r05_move_kernel_overread.md).  tests/test_gpu_poly_binned.py runs the index-checked build over this.
+    const uint32_t left = (uint32_t)A.n - (uint32_t)tile0;
+    const uint32_t here = left < (uint32_t)kMoveTile ? left : (uint32_t)kMoveTile;
     const int n_rows = 2 * A.rows;  // rows of polygon A, then of polygon B
     if (wave >= (uint32_t)kProducerWaves) {
         // ---- consumer: this thread's destination positions, in registers.  meta = li | class << 16 | rows_a << 24 | rows_b << 28
@@ -657,7 +679,7 @@ __global__ __launch_bounds__(kBinBlock, (kMoveTile <= 4096 ? 2 : 1) * kBinWaves 
         for (int j = 0; j < kMovePos; j++) {
             const uint32_t sp = (uint32_t)j * kConsumerThreads + tc;
             d_meta[j] = 0; d_stride[j] = 0; d_slot[j] = 0;
-            if (sp < n_valid) {
+            if (sp < n_valid && C2D_MOVE_OK(6, sp, kMoveTile) && C2D_MOVE_OK(7, s_sorted[sp], kMoveTile)) {
                 const uint32_t li = s_sorted[sp];
                 const uint32_t c = s_cls[li];
                 d_slot[j] = s_slot[li];
@@ -688,7 +710,7 @@ __global__ __launch_bounds__(kBinBlock, (kMoveTile <= 4096 ? 2 : 1) * kBinWaves 
                     const float2 v = sv[d_meta[j] & 0xffffu];
                     if (((live >> j) & 1u) && (uint32_t)r < rows_here && v.x == 1.2345e-30f && v.y == 5.4321e-30f) A.base[d_x[j]] = 0.0f;
 #else
-                    if (((live >> j) & 1u) && (uint32_t)r < rows_here) {
+                    if (((live >> j) & 1u) && (uint32_t)r < rows_here && C2D_MOVE_OK(8, d_x[j], A.lim_block) && C2D_MOVE_OK(9, d_y[j], A.lim_block)) {
                         const float2 v = sv[d_meta[j] & 0xffffu];
 #if defined(C2D_MOVE_STORE_WINDOW)      // (experiment: the same stores folded into a 32 MB window: is it DRAM or the way there?)
                         A.base[d_x[j] & 0x7fffffu] = v.x;
@@ -726,6 +748,7 @@ __global__ __launch_bounds__(kBinBlock, (kMoveTile <= 4096 ? 2 : 1) * kBinWaves 
                 } else
 #endif
                 if constexpr (FULL) {
+                    if (!C2D_MOVE_OK(10, row + li + 3, A.lim_in)) { fx[e] = fy[e] = make_float4(0, 0, 0, 0); continue; }
                     const v4f_u lx = __builtin_nontemporal_load(reinterpret_cast<const v4f_u*>(A.vx + row + li));
                     const v4f_u ly = __builtin_nontemporal_load(reinterpret_cast<const v4f_u*>(A.vy + row + li));
                     fx[e] = make_float4(lx.x, lx.y, lx.z, lx.w);
@@ -734,8 +757,9 @@ __global__ __launch_bounds__(kBinBlock, (kMoveTile <= 4096 ? 2 : 1) * kBinWaves 
                     float ax[4], ay[4];
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        ax[q] = li + q < here ? A.vx[row + li + q] : 0.0f;
-                        ay[q] = li + q < here ? A.vy[row + li + q] : 0.0f;
+                        const bool inside = li + q < here && C2D_MOVE_OK(11, row + li + q, A.lim_in);
+                        ax[q] = inside ? A.vx[row + li + q] : 0.0f;
+                        ay[q] = inside ? A.vy[row + li + q] : 0.0f;
                     }
                     fx[e] = make_float4(ax[0], ax[1], ax[2], ax[3]);
                     fy[e] = make_float4(ay[0], ay[1], ay[2], ay[3]);
@@ -1108,10 +1132,26 @@ int c2d_poly_bins_from_padded(c2d_ctx* ctx, const float* d_vx, const float* d_vy
     A.index = B->d_index;
     lap("small copies + memset");
     A.base = reinterpret_cast<float*>(base);
+#ifdef C2D_MOVE_CHECK
+    A.lim_in = (unsigned long long)2 * rows * n; A.lim_k = 2ull * n; A.lim_block = bytes / 4; A.lim_prefix = n_tiles * 256 + 256; A.lim_bins = n_bins;
+    unsigned long long* d_chk = nullptr;
+    C2D_BIN_HIP(hipMalloc(&d_chk, 32));
+    C2D_BIN_HIP(hipMemset(d_chk, 0, 32));
+    A.chk = d_chk;
+#endif
     if (bytes < (16ull << 30)) hipLaunchKernelGGL(poly_bin_move_kernel<uint32_t>, dim3(A.tiles_per_xcd * 8u), dim3(kBinBlock), 0, s, A);  // (n < 2^32)
     else hipLaunchKernelGGL(poly_bin_move_kernel<uint64_t>, dim3(A.tiles_per_xcd * 8u), dim3(kBinBlock), 0, s, A);
     C2D_BIN_HIP(hipStreamSynchronize(s));  // (the host vectors above must outlive their copies)
     workspace_stream_drained(ctx, s);
+#ifdef C2D_MOVE_CHECK
+    {
+        unsigned long long chk[4];
+        C2D_BIN_HIP(hipMemcpy(chk, d_chk, 32, hipMemcpyDeviceToHost));
+        (void)hipFree(d_chk);
+        if (chk[0]) fprintf(stderr, "[c2d move check] access %llu: index %llu, limit %llu (tile %llu, thread %llu; n %zu rows %d g %d bins %zu)\n", chk[0], chk[1], chk[2],
+                            chk[3] >> 32, chk[3] & 0xffffffffull, n, rows, g_, n_bins);
+    }
+#endif
     lap("move kernel");
 #undef C2D_BIN_HIP
     if (B->had_bad_counts) {

@@ -19,7 +19,7 @@ def _ensure_built():
     import subprocess
 
     pkg_dir = os.path.join(ROOT, "convex-2d-gpu-collision-detection_amd")
-    need = [os.path.join(pkg_dir, "lib", n) for n in ("libc2d.so", "libc2d_fmad1.so", "libc2d_fmad2.so", "libc2d_nopretest.so")]
+    need = [os.path.join(pkg_dir, "lib", n) for n in ("libc2d.so", "libc2d_fmad1.so", "libc2d_fmad2.so", "libc2d_nopretest.so", "libc2d_movecheck.so")]
     need += [os.path.join(pkg_dir, "lib-rehearsal", "libc2d.so")]
     need += [os.path.join(ROOT, "oracle", n) for n in ("libc2d_oracle.so", "libc2d_oracle_fmad1.so", "libc2d_oracle_fmad2.so")]
     need += [os.path.join(pkg_dir, "bin", b) for b in ("generate_dataset", "compute_collision_probability", "ztest")]

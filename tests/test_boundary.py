@@ -13,6 +13,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
+PKG_DIR = os.path.join(ROOT, "convex-2d-gpu-collision-detection_amd")
 
 
 def declared_symbols():
@@ -113,3 +114,31 @@ def test_headers_are_plain_c(tmp_path):
     # the struct sizes of utils.cu:74-104 (the program only uses header-inline code, so it links without libc2d)
     subprocess.run(["gcc", "-std=c11", inc, str(src), "-o", str(tmp_path / "t")], check=True)
     assert subprocess.run([str(tmp_path / "t")]).returncode == 0
+
+
+def test_no_kernel_selects_on_a_stale_scalar_condition():
+    """hipcc 7.2 compiled poly_bin_move_kernel's `min(n - tile0, 8192)` (64-bit) into an s_cselect on an SCC that an unrelated
+    s_add_i32 had set: the last tile's loads ran past the batch (profiles/notes_r05_move_kernel_overread.md).  Every shipped
+    build is disassembled and searched for that shape (tests/tools/scc_scan.py); the scanner is checked on the miscompiled
+    sequence itself."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("scc_scan", os.path.join(ROOT, "tests", "tools", "scc_scan.py"))
+    scc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(scc)
+    bad = """_ZN3c2d20poly_bin_move_kernelIjEEvNS_11BinMoveArgsE:
+	s_sub_u32 s0, s42, s44
+	s_subb_u32 s1, s43, s45
+	s_lshl_b32 s33, s34, 1
+	v_cmp_lt_u64_e32 vcc, s[0:1], v[0:1]
+	s_add_i32 s35, s33, -1
+	s_mov_b64 s[2:3], -1
+	s_cbranch_vccz .LBB5_289
+; %bb.29:
+	s_cselect_b32 s48, s0, 0x2000
+"""
+    good = bad.replace("v_cmp_lt_u64_e32 vcc, s[0:1], v[0:1]\n\ts_add_i32 s35, s33, -1", "s_add_i32 s35, s33, -1\n\ts_cmpk_lt_u32 s0, 0x2000")
+    assert len(scc.scan_lines(bad.splitlines(), "bad")) == 1 and scc.scan_lines(good.splitlines(), "good") == []
+    libs = [os.path.join(PKG_DIR, "lib", n) for n in ("libc2d.so", "libc2d_fmad1.so", "libc2d_fmad2.so", "libc2d_nopretest.so", "libc2d_movecheck.so")]
+    libs.append(os.path.join(PKG_DIR, "lib-rehearsal", "libc2d.so"))
+    for lib in libs:
+        assert scc.scan_library(lib) == [], lib

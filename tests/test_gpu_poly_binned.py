@@ -1,6 +1,8 @@
 """GPU parity tests of the binned polygon path (include/c2d.h "binned polygon batches") through the C-ABI: every boolean
 of every bin equals the oracle's for the same polygons, whatever the bin sizes, row counts, strides and densities; the
 device binning of a padded batch returns the padded entry point's results in the padded order."""
+import os
+
 import numpy as np
 import pytest
 
@@ -245,3 +247,26 @@ def test_binned_differential_fuzz(eng, oracle, wl):
         h.close()
         for b in bufs + [d_cnt]:
             b.free()
+
+
+@pytest.mark.parametrize("n,rows,g,kmin", [(20_000, 13, 1, 4), (63, 12, 11, 10), (4097, 16, 14, 10), (4096, 16, 2, 6), (8192, 9, 3, 2), (70_001, 7, 5, 7)])
+def test_move_kernel_stays_inside_its_arrays(pkg, oracle, wl, capfd, n, rows, g, kmin):
+    """The index-checked build of the binning pass (make lib-movecheck): every index poly_bin_move_kernel forms is compared with
+    its array's size and the first offender is reported on stderr instead of being used.  A differential fuzz met a memory
+    fault at the first shape: as hipcc 7.2 had compiled it, the kernel read its last, partial tile as a whole one, up to 8191
+    floats past the end of vx / vy — values nobody used, so every result was right, and the reads only faulted when the batch
+    ended where a mapping ended (profiles/notes_r05_move_kernel_overread.md).  The shapes: that one, partial tiles of one and of
+    several tiles, a batch that is exactly one 4096-pair half tile and one that is exactly a tile."""
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "convex-2d-gpu-collision-detection_amd", "lib", "libc2d_movecheck.so")
+    e = pkg.Engine(0, lib_path=lib)
+    try:
+        vx, vy, k = wl.random_convex_polygons(n, seed=600_401 + n, kmin=kmin, kmax=rows, extent=1.5, rows=rows)
+        ref, ref_cnt = oracle.sat_poly_pairs(vx, vy, k)
+        capfd.readouterr()
+        out, cnt, bins = run_from_padded(e, vx, vy, k, rows, g)
+        err = capfd.readouterr().err
+        bins.close()
+    finally:
+        e.close()
+    assert "[c2d move check]" not in err, err
+    assert np.array_equal(out, ref) and cnt == ref_cnt

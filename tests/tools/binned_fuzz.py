@@ -30,12 +30,15 @@ def main():
     rng = np.random.default_rng(seed)
     eng = pkg.Engine(0)
     pairs = 0
+    verbose = bool(os.environ.get("C2D_FUZZ_VERBOSE"))   # every configuration is named BEFORE it runs: a GPU fault then names its input
     for it in range(configs):
         if it % 3 == 2:  # a padded batch through the device binning
             n = int(rng.choice([1, 63, 64, 65, 1000, 4095, 4096, 4097, 20_000, 70_001]))
             rows = int(rng.integers(1, 17))
             g = int(rng.integers(1, rows + 1))
             kmin = int(rng.integers(1, rows + 1))
+            if verbose:
+                print(f"{it}: from_padded n={n} rows={rows} g={g} kmin={kmin}", flush=True)
             vx, vy, k = wl.random_convex_polygons(n, seed=seed * 100_000 + it, kmin=kmin, kmax=rows, extent=float(rng.choice([0.5, 1.5, 6.0])), rows=rows)
             ref, ref_cnt = oracle.sat_poly_pairs(vx, vy, k)
             out, cnt, bins = bt.run_from_padded(eng, vx, vy, k, rows, g)
@@ -47,6 +50,8 @@ def main():
             specs = [(int(rng.integers(1, 17)), int(rng.integers(1, 17)), int(rng.choice([1, 5, 63, 64, 65, 300, 2000, 5000]))) for _ in range(nb)]
             counted = bool(rng.integers(0, 2))
             extent = float(rng.choice([0.5, 1.0, 2.0, 6.0]))
+            if verbose:
+                print(f"{it}: bins counted={counted} extent={extent} {specs}", flush=True)
             bins, host, bufs = bt._upload_user_bins(eng, rng, specs, extent, wl, counted, int(rng.choice([0, 0, 3, 64])), seed=seed * 100_000 + it * 100)
             h = eng.poly_bins_create(bins)
             d_cnt = eng.zeros(1, np.uint64)
