@@ -15,6 +15,8 @@ import tempfile
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 
 READERS = ("s_cselect_b32", "s_cselect_b64", "s_cmov_b32", "s_cmov_b64", "s_cbranch_scc0", "s_cbranch_scc1")
+CARRY_READERS = ("s_addc_u32", "s_subb_u32")            # ... and the carry of a wider addition: only another addition's may feed them
+CARRY = re.compile(r"^(s_add_u32|s_sub_u32|s_addc_u32|s_subb_u32|s_cmp_\w+|s_cmpk_\w+)$")  # (a comparison: a boolean added as the carry)
 # SALU instructions that leave SCC alone
 KEEPS = re.compile(r"^(s_mov|s_movk|s_cselect|s_cmov|s_mul_|s_mulk|s_load|s_buffer_load|s_store|s_waitcnt|s_nop|s_barrier|s_bfm|s_sext|s_pack|s_getpc|s_setpc|s_swappc|"
                    r"s_ff1|s_ff0|s_flbit|s_brev|s_bitset|s_cbranch|s_branch|s_endpgm|s_sleep|s_setprio|s_setreg|s_getreg|s_dcache|s_icache|s_memtime|s_memrealtime|"
@@ -40,10 +42,10 @@ def scan_lines(lines, path):
             func, window = f.group(1) or f.group(2), []
             continue
         op = t.split()[0]
-        if op in READERS:
+        if op in READERS or op in CARRY_READERS:
             for m, prev_op, prev in reversed(window):
                 if prev_op.startswith("s_") and not KEEPS.match(prev_op):
-                    if not CONDITION.match(prev_op):
+                    if not (CONDITION if op in READERS else CARRY).match(prev_op):
                         suspects.append((path, n, func, t, m, prev))
                     break
         window.append((n, op, t))
