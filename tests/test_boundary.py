@@ -138,6 +138,9 @@ def test_no_kernel_selects_on_a_stale_scalar_condition():
 """
     good = bad.replace("v_cmp_lt_u64_e32 vcc, s[0:1], v[0:1]\n\ts_add_i32 s35, s33, -1", "s_add_i32 s35, s33, -1\n\ts_cmpk_lt_u32 s0, 0x2000")
     assert len(scc.scan_lines(bad.splitlines(), "bad")) == 1 and scc.scan_lines(good.splitlines(), "good") == []
+    # the same with the reader at the branch's TARGET (the scanner follows the control-flow graph, not the text order)
+    across = bad.replace("s_cbranch_vccz .LBB5_289\n; %bb.29:\n", "s_cbranch_vccnz .LBB5_30\n\ts_endpgm\n.LBB5_30:\n")
+    assert len(scc.scan_lines(across.splitlines(), "across")) == 1
     libs = [os.path.join(PKG_DIR, "lib", n) for n in ("libc2d.so", "libc2d_fmad1.so", "libc2d_fmad2.so", "libc2d_nopretest.so", "libc2d_movecheck.so")]
     libs.append(os.path.join(PKG_DIR, "lib-rehearsal", "libc2d.so"))
     for lib in libs:

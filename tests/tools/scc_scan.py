@@ -27,28 +27,70 @@ CONDITION = re.compile(r"^(s_cmp_|s_cmpk_|s_bitcmp|s_and_|s_or_|s_xor_|s_andn2_|
 
 
 def scan_lines(lines, path):
-    """lines: compiler assembly (labels `.LBBn_m:`, functions `name:`) or llvm-objdump --symbolize-operands output (`<Ln>:`, `addr <name>:`)"""
-    suspects, func = [], "?"
-    window = []  # straight-line instructions since the last label
+    """lines: compiler assembly (labels `.LBBn_m:`, functions `name:`) or llvm-objdump --symbolize-operands output (`<Ln>:`, `addr <name>:`).
+    Per function a control-flow graph of basic blocks; for every reader the SCC writers that REACH it (backwards through blocks
+    that leave SCC alone, over fall-through and branch edges) are classified."""
+    suspects = []
+    func, blocks, labels = "?", [], {}   # a block: {"ins": [(line, op, text)], "falls": bool, "target": label or None}
+
+    def new_block():
+        blocks.append({"ins": [], "falls": True, "target": None})
+
+    def writes_scc(op):
+        return op.startswith("s_") and not KEEPS.match(op)
+
+    def finish():
+        preds = {i: [] for i in range(len(blocks))}
+        for i, b in enumerate(blocks):
+            if b["falls"] and i + 1 < len(blocks):
+                preds[i + 1].append(i)
+            if b["target"] in labels:
+                preds[labels[b["target"]]].append(i)
+        for i, b in enumerate(blocks):
+            for k, (n, op, t) in enumerate(b["ins"]):
+                if op not in READERS and op not in CARRY_READERS:
+                    continue
+                reaching = next(([x] for x in reversed(b["ins"][:k]) if writes_scc(x[1])), None)
+                if reaching is None:  # none in this block: the last writer of every block that reaches its top
+                    reaching, seen, todo = [], {i}, list(preds[i])
+                    while todo:
+                        j = todo.pop()
+                        if j in seen:
+                            continue
+                        seen.add(j)
+                        w = next((x for x in reversed(blocks[j]["ins"]) if writes_scc(x[1])), None)
+                        if w is not None:
+                            reaching.append(w)
+                        else:
+                            todo += preds[j]
+                for m, wop, wt in reaching:
+                    if not (CONDITION if op in READERS else CARRY).match(wop):
+                        suspects.append((path, n, func, t, m, wt))
+
+    new_block()
     for n, line in enumerate(lines, 1):
-        t = line.split("//")[0].strip()
+        t = line.split("//")[0].split(";")[0].strip()
         if not t or t.startswith((";", ".")) and not t.startswith(".LBB"):
             continue
-        if t.startswith(".LBB") or re.match(r"^[0-9a-f]+ <L\d+>:$", t):
-            window = []  # a join point: the writer may be on another path
+        lab = re.match(r"^(?:(\.LBB\w+)|[0-9a-f]+ <(L\d+)>):$", t)
+        if lab:
+            new_block()
+            labels[lab.group(1) or lab.group(2)] = len(blocks) - 1
             continue
         f = re.match(r"^(?:[0-9a-f]+ <([^>]+)>|([A-Za-z_][\w$.]*)):$", t)
         if f:
-            func, window = f.group(1) or f.group(2), []
+            finish()
+            func, blocks, labels = f.group(1) or f.group(2), [], {}
+            new_block()
             continue
         op = t.split()[0]
-        if op in READERS or op in CARRY_READERS:
-            for m, prev_op, prev in reversed(window):
-                if prev_op.startswith("s_") and not KEEPS.match(prev_op):
-                    if not (CONDITION if op in READERS else CARRY).match(prev_op):
-                        suspects.append((path, n, func, t, m, prev))
-                    break
-        window.append((n, op, t))
+        blocks[-1]["ins"].append((n, op, t))
+        if op.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc", "s_swappc")):
+            blocks[-1]["falls"] = op.startswith("s_cbranch") or op.startswith("s_swappc")
+            if op.startswith(("s_cbranch", "s_branch")):
+                blocks[-1]["target"] = t.split()[-1]
+            new_block()
+    finish()
     return suspects
 
 
