@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool: look for the miscompilation that made poly_bin_move_kernel over-read (profiles/notes_r05_move_kernel_overread.md)
-in gfx950 assembly: an instruction that READS the scalar condition code (s_cselect, s_cmov, s_cbranch_scc0/1) whose nearest
-earlier SCC writer in straight-line code is not a comparison or a mask operation (e.g. an s_add_i32 of unrelated values).
+in gfx950 assembly: an instruction that READS the scalar condition code (s_cselect, s_cmov, s_cbranch_scc0/1) with a reaching
+SCC writer (over the function's control-flow graph) that is not a comparison, a mask operation or a carry (e.g. an s_add_i32 of unrelated values).
 usage: scc_scan.py FILE...   FILE.s (hipcc -S --cuda-device-only) or a built library / object (its gfx950 code objects are taken out
 of the offload bundles and disassembled with llvm-objdump); prints every suspect with its function and context; exit 1 if any.
 tests/test_boundary.py runs scan_library over the shipped libc2d.so."""
