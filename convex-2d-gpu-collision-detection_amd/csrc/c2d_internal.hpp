@@ -107,7 +107,7 @@ constexpr int kMaxGrid = 1 << 24;  // blocks per launch; kernels grid-stride bey
 // per stamp the ticket it must reach.  The check is one read of the workspace block (167 KB: the words and their stamps) on a
 // stream the ctx owns, made only when the stream changes while tickets are outstanding: a word counts as retired when its
 // stamp has reached its ticket AND the word itself reads zero again (c2d_count.hpp: that pair is the final state whatever order
-// the kernel's two atomics land in, so the kernels need no fence).  The hot path pays one 64-bit kernel argument and one
+// the kernel's two atomics land in, so the kernels need no fence).  The hot path pays one 32-bit kernel argument and one
 // non-returning atomic per completed word.  Round 4 asked the runtime instead (hipStreamQuery on the previous call's stream) — a handle whose
 // lifetime belongs to the caller; profiles/notes_r05_workspace_guard.md has what that cost.
 //
