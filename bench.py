@@ -117,7 +117,7 @@ def self_launch(n_gpus: int) -> int:
 
     limit_s = float(os.environ.get("C2D_BENCH_LAUNCH_TIMEOUT_S", "3000"))
     returncode, out_text = 1, ""
-    for attempt in range(3):
+    for _attempt in range(3):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
@@ -1031,7 +1031,7 @@ def cpu_baselines_and_parity(R) -> None:
                                        "parity": mc_poly["parity"]}
         if mc_poly is not None and "scenes" in mc_poly:  # its adaptive dataset: the first scenes of the shard, hits and stop points, then the oracle's rate
             pp_tab, ps_tab, p_scn, p_rob9, g_h, g_u, base0 = mc_poly_scenes_keep
-            chk, done_s, smp = 0, 0, 0
+            chk, smp = 0, 0
             c0 = time.perf_counter()
             while chk < len(p_scn):
                 m = min(500, len(p_scn) - chk)
