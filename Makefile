@@ -41,7 +41,7 @@ clean:
 .PHONY: all lib oracle drivers tools clean lib-fmad lib-nopretest lib-rehearsal lib-mcstats lib-mcclock lib-ab-stamps lib-movecheck
 
 # developer tools (not shipped in libc2d.so)
-TOOLS := $(CSRC)/tools/sat_tune $(CSRC)/tools/pose_probe $(CSRC)/tools/clock_probe $(CSRC)/tools/instr_probe $(CSRC)/tools/store_pattern_probe $(CSRC)/tools/stream_lifetime_probe
+TOOLS := $(CSRC)/tools/sat_tune $(CSRC)/tools/pose_probe $(CSRC)/tools/clock_probe $(CSRC)/tools/instr_probe $(CSRC)/tools/store_pattern_probe $(CSRC)/tools/stream_lifetime_probe $(CSRC)/tools/load_policy_probe
 tools: $(TOOLS)
 # (the instruction probe includes the Monte-Carlo legs' mixes when profiles/valu_issue.py has generated them)
 $(CSRC)/tools/instr_probe: $(wildcard $(CSRC)/tools/instr_probe_mixes.inc)

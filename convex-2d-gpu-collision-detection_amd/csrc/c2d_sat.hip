@@ -70,6 +70,9 @@ C2D_DEV uint32_t bits_to_bytes4(uint32_t b) { return (b & 1u) | ((b & 2u) << 7) 
 // ---- rectangle pairs, vertex format ------------------------------------------
 // VEC == 4: planes read as float4 (16 B / lane), results written as one dword.
 // VEC == 1: scalar loads; used for the tail and for unaligned buffers.
+#ifndef C2D_SAT_PRIO
+#define C2D_SAT_PRIO 0
+#endif
 template <int VEC, int BLOCK>
 __global__ __launch_bounds__(BLOCK, (VEC == 4 ? 5 : 1)) void sat_rect_verts_kernel(Planes16 P, size_t first, size_t n_groups,
                                                                 uint8_t* __restrict__ out,
@@ -80,8 +83,17 @@ __global__ __launch_bounds__(BLOCK, (VEC == 4 ? 5 : 1)) void sat_rect_verts_kern
     for (size_t g = (size_t)blockIdx.x * BLOCK + threadIdx.x; g < n_groups; g += stride) {
         if constexpr (VEC == 4) {
             f32x4 v[16];
+#if C2D_SAT_PRIO == 1  // (experiment: the wave's address arithmetic and loads ahead of older waves' arithmetic)
+            __builtin_amdgcn_s_setprio(3);
+#endif
 #pragma unroll
             for (int k = 0; k < 16; k++) v[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P.p[k]) + g);
+#if C2D_SAT_PRIO == 1
+            __builtin_amdgcn_s_setprio(0);
+#elif C2D_SAT_PRIO == 2  // (experiment: a wave whose data has arrived ahead of younger waves, so that it frees its slot sooner)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_setprio(3);
+#endif
             const uint32_t packed = bits_to_bytes4(collide_pairs<4>([&v](int e, auto how, float (&r1)[8], float (&r2)[8]) {
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
