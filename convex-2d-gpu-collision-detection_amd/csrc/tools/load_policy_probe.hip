@@ -8,6 +8,7 @@
 //   buffer aux=k  raw buffer loads with the gfx940+ cache-policy bits of the instruction: sc0 = 1, nt = 2, sc1 = 16 (all eight combinations)
 // and for the best of them the stores with and without the non-temporal hint, the grid as resident blocks that stride, and the same
 // stream with arithmetic on the loaded values (0 .. 2048 VALU instructions per lane; the product kernel issues 928).
+// A second part does the same for the polygon kernels' shape: one pair per lane, 4-byte loads of 16 / 38 / 64 rows, one result byte.
 // Usage: load_policy_probe [pairs]     (default 1e7: 650 MB per pass; prints microseconds per pass and GB/s, median of 5 timings of 40 passes)
 #include <hip/hip_runtime.h>
 
@@ -62,6 +63,36 @@ __global__ __launch_bounds__(64) void stream_kernel(const float* __restrict__ pl
         const uint32_t bits = (acc.x > 0.f ? 1u : 0u) | (acc.y > 0.f ? 0x100u : 0u) | (acc.z > 0.f ? 0x10000u : 0u) | (acc.w > 0.f ? 0x1000000u : 0u);
         if (NT_STORE) __builtin_nontemporal_store(bits, out + g);
         else out[g] = bits;
+    }
+}
+
+// The polygon kernels' shape: a single-wave block takes 64 pairs (TILES x 64 with TILES > 1), one pair per lane, and reads ROWS
+// f32 rows of n values with 4-byte loads (a wave's request for a row is 256 contiguous bytes); one result byte per pair.
+// BUF: raw buffer loads with the row offset in an SGPR (what sat_poly_binned_kernel does) instead of global loads.
+template <int ROWS, int TILES, bool BUF>
+__global__ __launch_bounds__(64) void row_stream_kernel(const float* __restrict__ rows, size_t n, uint8_t* __restrict__ out)
+{
+#pragma unroll 1
+    for (int t = 0; t < TILES; t++) {
+        const size_t i = ((size_t)blockIdx.x * TILES + t) * 64 + threadIdx.x;
+        if (i >= n) return;
+        float v[ROWS];
+        if constexpr (BUF) {
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rows) + ((size_t)blockIdx.x * TILES + t) * 64, 0, 0x7fffffff, 0x00020000);
+            uint32_t soff = 0;
+#pragma unroll
+            for (int k = 0; k < ROWS; k++) {
+                v[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)(threadIdx.x * 4), (int)soff, 2));
+                soff += (uint32_t)(n * 4);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < ROWS; k++) v[k] = __builtin_nontemporal_load(rows + (size_t)k * n + i);
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < ROWS; k++) acc += v[k];
+        __builtin_nontemporal_store((uint8_t)(acc > 0.f ? 1 : 0), out + i);
     }
 }
 
@@ -136,5 +167,34 @@ int main(int argc, char** argv)
     CHECK(hipGetLastError());
     CHECK(hipFree(planes));
     CHECK(hipFree(out));
+    // ---- the polygon kernels' shape (sat_poly_binned_kernel: 64 pairs per wave, 4-byte loads of about 38 rows of 256 bytes)
+    {
+        constexpr int kMaxRows = 64;
+        // (the raw-buffer form keeps the whole batch below 2 GiB from a tile's base: rows x pairs x 4 bytes)
+        const size_t np = n > 8000000 ? 8000000 : n;
+        float* rows = nullptr;
+        uint8_t* o8 = nullptr;
+        CHECK(hipMalloc(&rows, (size_t)kMaxRows * np * sizeof(float)));
+        CHECK(hipMalloc(&o8, np));
+        CHECK(hipMemset(rows, 0x3c, (size_t)kMaxRows * np * sizeof(float)));
+        printf("# polygon shape: %zu pairs, one pair per lane, ROWS 4-byte loads per lane, one result byte\n", np);
+        auto report_rows = [&](const char* name, int nrows, double us) {
+            const double b = ((double)nrows * 4 + 1) * (double)np;
+            printf("%-44s %8.1f us  %7.1f GB/s  %.3f of 8 TB/s\n", name, us, b / us / 1e3, b / us / 1e3 / 8000.0);
+            fflush(stdout);
+        };
+#define RUNR(name, ROWS, TILES, BUF) report_rows(name, ROWS, time_us([&] { hipLaunchKernelGGL((row_stream_kernel<ROWS, TILES, BUF>), dim3((unsigned)((np + 64 * TILES - 1) / (64 * TILES))), dim3(64), 0, s, rows, np, o8); }, s))
+        RUNR("16 rows, global nt, 1 tile per wave", 16, 1, false);
+        RUNR("38 rows, global nt, 1 tile per wave", 38, 1, false);
+        RUNR("38 rows, global nt, 2 tiles per wave", 38, 2, false);
+        RUNR("38 rows, buffer nt + soffset, 1 tile", 38, 1, true);
+        RUNR("38 rows, buffer nt + soffset, 2 tiles", 38, 2, true);
+        RUNR("38 rows, buffer nt + soffset, 4 tiles", 38, 4, true);
+        RUNR("64 rows, global nt, 1 tile per wave", 64, 1, false);
+        RUNR("64 rows, buffer nt + soffset, 1 tile", 64, 1, true);
+        CHECK(hipGetLastError());
+        CHECK(hipFree(rows));
+        CHECK(hipFree(o8));
+    }
     return 0;
 }
