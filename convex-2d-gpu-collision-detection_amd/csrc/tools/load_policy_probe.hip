@@ -150,6 +150,8 @@ int main(int argc, char** argv)
     RUN("buffer sc0 sc1 nt, nt store", 2, 19, true, blocks);
     RUN("global nt, plain store", 1, 0, false, blocks);
     RUN("buffer nt, plain store", 2, 2, false, blocks);
+    RUN("global nt, nt store, 2 groups per block", 1, 0, true, (blocks + 1) / 2);
+    RUN("global nt, nt store, 3 groups per block", 1, 0, true, (blocks + 2) / 3);
     RUN("global nt, nt store, 8192 resident blocks", 1, 0, true, 8192);
     RUN("global nt, nt store, 4096 resident blocks", 1, 0, true, 4096);
     RUN("buffer sc1 nt, nt store, 8192 resident", 2, 18, true, 8192);
