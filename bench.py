@@ -120,7 +120,9 @@ def self_launch(n_gpus: int) -> int:
     for _attempt in range(3):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+        # (its own session: on a timeout the launcher AND its ranks are signalled as one process group — SIGKILL to the launcher
+        # alone cannot be forwarded and would leave the ranks holding their GPUs)
+        child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
         # The ranks' diagnostics are relayed AS THEY COME (a run that hangs in the rendezvous or in RCCL's start-up must not be
         # silent), and scanned: the port retry below applies only while no rank has said anything of its own yet.
         seen = {"addr_in_use": False, "rank_lines": 0, "stdout": []}
@@ -140,17 +142,39 @@ def self_launch(n_gpus: int) -> int:
         threads = [threading.Thread(target=relay, daemon=True), threading.Thread(target=collect, daemon=True)]
         for t in threads:
             t.start()
+        import signal
+
+        def forward(signum, _frame, child=child):  # a signal to this parent (a `timeout` wrapper, Ctrl-C) reaches the ranks' own session too
+            try:
+                os.killpg(child.pid, signum)
+            except (ProcessLookupError, PermissionError):
+                pass
+
+        previous = {sg: signal.signal(sg, forward) for sg in (signal.SIGTERM, signal.SIGINT)}
+        timed_out = False
         try:
             returncode = child.wait(timeout=limit_s)
         except subprocess.TimeoutExpired:
-            child.kill()
-            returncode = child.wait()
-            sys.stderr.write(f"[bench] the {n_gpus} ranks did not finish within {limit_s:.0f} s ($C2D_BENCH_LAUNCH_TIMEOUT_S): killed\n")
+            timed_out = True
+            for sig in (signal.SIGTERM, signal.SIGKILL):  # SIGKILL goes to the group even when the launcher left on SIGTERM: a rank may not have
+                try:
+                    os.killpg(child.pid, sig)  # (the session leader's pid is the group's id)
+                except (ProcessLookupError, PermissionError):
+                    break
+                try:
+                    child.wait(timeout=10.0)
+                except subprocess.TimeoutExpired:
+                    pass
+            returncode = child.wait() or 1
+            sys.stderr.write(f"[bench] the {n_gpus} ranks did not finish within {limit_s:.0f} s ($C2D_BENCH_LAUNCH_TIMEOUT_S): "
+                             "the launcher's process group was terminated\n")
+        for sg, h in previous.items():
+            signal.signal(sg, h)
         for t in threads:
             t.join(timeout=10)
         out_text = "".join(seen["stdout"])
-        if returncode == 0 or not seen["addr_in_use"] or seen["rank_lines"] or '"metric"' in out_text:
-            break
+        if returncode == 0 or timed_out or not seen["addr_in_use"] or seen["rank_lines"] or '"metric"' in out_text:
+            break  # (never a second set of ranks after a timeout)
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
@@ -317,6 +341,73 @@ def setup(args, R) -> None:
         torch.cuda.synchronize()  # (two communicators live in this process — c2d's and torch's: never a collective of each in flight at once)
         dist.barrier()
         torch.cuda.synchronize()
+    # ---- what makes an N > 1 line readable: every rank's own kernel time, and the closing reduce by itself ----
+    on_device = args.backend == "nccl"
+
+    def gather_ranks(vals):
+        """Every rank's row of a few doubles, in rank order: ONE all_gather, always AFTER a timed region."""
+        if not use_dist:
+            return [[float(v) for v in vals]]
+        t = torch.tensor([float(v) for v in vals], dtype=torch.float64, device=dev if on_device else None)
+        rows = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(rows, t)
+        return [r.tolist() for r in rows]
+
+    def rank_spread(kernel_ms, units, roofline=None, work=None):
+        """kernel_ms = this rank's HIP-event time of one launch (or of the leg's one device loop), units = what that launch processed
+        on this rank, work = what its roofline counts when that is not the unit (drawn samples of an adaptive loop).  Returns
+        ({min, median, max, ...} of kernel_ms over ranks, sum of units / slowest rank's time) and writes `kernel_ms_ranks` and
+        `frac_slowest_rank` into the roofline: `frac` is rank 0's, a curve is bounded by the slowest rank's."""
+        rows = gather_ranks([kernel_ms, units, units if work is None else work])
+        ms = np.array([r[0] for r in rows])
+        slow = int(ms.argmax())
+        spread = {"min": round(float(ms.min()), 5), "median": round(float(np.median(ms)), 5), "max": round(float(ms.max()), 5),
+                  "ranks": len(rows), "slowest_rank": slow}
+        kernels_only = sum(r[1] for r in rows) / (float(ms.max()) * 1e-3) if ms.max() > 0 else None
+        if roofline is not None:
+            me = rows[rank if use_dist else 0]
+            roofline["kernel_ms_ranks"] = spread
+            roofline["frac_slowest_rank"] = round(roofline["frac"] * (rows[slow][2] / me[2]) * (me[0] / rows[slow][0]), 4) if me[2] and rows[slow][0] else None
+        return spread, kernels_only
+
+    def time_reduce(numel=1, before=None, reps=20):
+        """The closing all_reduce_sum by itself, microseconds, in a SEPARATE untimed pass: its own event pair on the kernels' stream
+        (opened behind one launch of `before`, the leg's step, so that the stream is as busy as where the timed region meets the
+        reduce) and the host's wall time of call + synchronize.  None with a single rank and no process group."""
+        if not use_dist:
+            return None
+        scratch = torch.zeros(numel, dtype=torch.int64, device=dev)
+        dist.barrier()
+        torch.cuda.synchronize()
+        ev_us, host_us = [], []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if before is not None:
+                before()
+            h0 = time.perf_counter()
+            e0.record(stream)
+            all_reduce_sum(scratch)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            host_us.append((time.perf_counter() - h0) * 1e6)
+            ev_us.append(e0.elapsed_time(e1) * 1e3)
+        ev, ho = np.array(ev_us), np.array(host_us)
+        return {"reps": reps, "counters": numel, "event_median": round(float(np.median(ev)), 1), "event_min": round(float(ev.min()), 1),
+                "event_max": round(float(ev.max()), 1), "host_median": round(float(np.median(ho)), 1),
+                "note": "separate untimed pass; event pair on the kernels' stream around the reduce alone, each behind one launch of the leg's "
+                        "step (so it includes waiting for the slowest peer's step); host = wall time of call + synchronize, which also "
+                        "waits for that launch to drain"}
+
+    barrier_us = None
+    if use_dist:  # what one dist.barrier() + synchronize costs the host here: each timed region contains one
+        b = []
+        for _ in range(10):
+            h0 = time.perf_counter()
+            dist.barrier()
+            torch.cuda.synchronize()
+            b.append((time.perf_counter() - h0) * 1e6)
+        barrier_us = round(float(np.median(b)), 1)
+    R.barrier_us, R.rank_spread, R.time_reduce = barrier_us, rank_spread, time_reduce
     # what the later legs and the result line read
     R.all_reduce_sum, R.args, R.cdist, R.counts, R.dev, R.dev_info, R.dist, R.eng, R.pkg, R.rank = all_reduce_sum, args, cdist, counts, dev, dev_info, dist, eng, pkg, rank
     R.rccl_library, R.rccl_version, R.real_stdout, R.reduce_impl, R.sh, R.shd, R.stream, R.torch, R.use_dist, R.wl = rccl_library, rccl_version, real_stdout, reduce_impl, sh, shd, stream, torch, use_dist, wl
@@ -403,6 +494,7 @@ def leg_pairs(R) -> None:
     step_ms = step_distribution(step, min(args.steps, 100))
     pairs_total = n * world * args.steps
     value = pairs_total / elapsed
+    reduce_us = R.time_reduce(1, before=step)
     collide_rate = count_after_timed / (n * world * args.steps)
 
     achieved_gbs = BYTES_PER_PAIR * n / (kernel_ms * 1e-3) / 1e9
@@ -415,6 +507,15 @@ def leg_pairs(R) -> None:
                 "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": BYTES_PER_PAIR * n, "kernel_ms": round(kernel_ms, 5),
                 "step_ms_distribution": step_ms}
+    spread, value_kernels_only = R.rank_spread(kernel_ms, n, roofline)
+    # how the timed region divides: the slowest rank's K launches, and what is left (launch gaps, the reduce, one barrier, synchronize)
+    scaling_detail = {"timed_region_ms": round(elapsed * 1e3, 4), "kernels_ms_slowest_rank": round(spread["max"] * args.steps, 4),
+                      "timed_region_minus_kernels_us": round((elapsed * 1e3 - spread["max"] * args.steps) * 1e3, 1),
+                      "barrier_us": R.barrier_us,
+                      "note": "value = all ranks' pairs / timed_region (contract: barrier + synchronize on both sides, max over ranks); "
+                              "value_kernels_only = all ranks' pairs per launch / the slowest rank's average launch time by HIP events: a fixed "
+                              "closing cost of the 2-ms region (reduce_us, barrier_us) lowers `value` at any N and is not a scaling loss of the kernels"}
+    R.reduce_us, R.scaling_detail, R.value_kernels_only = reduce_us, scaling_detail, value_kernels_only
     # what the later legs and the result line read
     R.barrier, R.collide_rate, R.count_after_timed, R.elapsed, R.n, R.out, R.plane_ptrs, R.planes, R.pose, R.pose_ptrs = barrier, collide_rate, count_after_timed, elapsed, n, out, plane_ptrs, planes, pose, pose_ptrs
     R.prewarm, R.roofline, R.step_distribution, R.value = prewarm, roofline, step_distribution, value
@@ -599,6 +700,7 @@ def leg_mc(R) -> None:
         mc = {"metric": "mc_samples_per_s", "value": S * world * args.mc_reps / mel, "samples_per_gpu": S, "reps": args.mc_reps,
               "kernel_ms": round(mc_kernel_ms, 4), "probability": p, "scene": "config3: robot 4.07x1.74 at (3,1) th=0.6, obstacle 2x1, sigma=(.3,.3,.2,0,0)",
               "bound": "valu", "note": "~0 HBM bytes per sample; VALU/transcendental bound (DESIGN.md)"}
+        mc["reduce_us"] = R.time_reduce(1, before=mc_step, reps=5)
         c = counts.get("mc_pair.config3")
         if c:  # the count belongs to THIS scene (wl.MC_PAIR_SCENE) and kernel build
             lane_ops = S / (mc_kernel_ms * 1e-3) * c["valu_instr_per_sample"] / 1e12
@@ -608,6 +710,7 @@ def leg_mc(R) -> None:
                               "instr_source": c.get("source")}
             held_clock(mc["roofline"], c)
             issue_weighted(mc["roofline"], c, S / (mc_kernel_ms * 1e-3) * c["valu_instr_per_sample"] / 64)
+        mc["kernel_ms_ranks"], mc["value_kernels_only"] = R.rank_spread(mc_kernel_ms, S, mc.get("roofline"))
     # what the later legs and the result line read
     R.S, R.mc, R.mc_hits_one_step, R.sc = S, mc, mc_hits_one_step, sc
 
@@ -658,6 +761,8 @@ def leg_mc_poly(R) -> None:
                                    "valu_instr_per_sample": c["valu_instr_per_sample"], "instr_source": c.get("source")}
             held_clock(mc_poly["roofline"], c)
             issue_weighted(mc_poly["roofline"], c, PS / (mc_poly_ms * 1e-3) * c["valu_instr_per_sample"] / 64)
+        mc_poly["kernel_ms_ranks"], mc_poly["value_kernels_only"] = R.rank_spread(mc_poly_ms, PS, mc_poly.get("roofline"))
+        mc_poly["reduce_us"] = R.time_reduce(1, before=mc_poly_step, reps=5)
         # the adaptive loop over a dataset of polygon scenes (c2d_mc_poly_scenes): random obstacle polygons of 3..16 vertices, a 9-gon
         # robot, the stop rule of config 4.  Scenes shard over ranks like config 4's (scene_id_base = the shard's first scene).
         PN = args.poly_scenes
@@ -678,6 +783,7 @@ def leg_mc_poly(R) -> None:
             pq0 = time.perf_counter()
             p_total, p_iters = poly_scenes_step()
             torch.cuda.synchronize()
+            pq_own_ms = (time.perf_counter() - pq0) * 1e3  # this rank's own call (synchronous: it returns the totals), before the barrier
             barrier()
             pqel = shd.max_over_ranks(time.perf_counter() - pq0, dev)
             p_tot_t = torch.tensor([p_total], dtype=torch.int64, device=dev)
@@ -695,6 +801,8 @@ def leg_mc_poly(R) -> None:
                                                  "note": "instructions per DRAWN sample, as for config 4"}
                 held_clock(mc_poly["scenes"]["roofline"], cq)
                 issue_weighted(mc_poly["scenes"]["roofline"], cq, p_total / pqel * cq["valu_instr_per_sample"] / 64)
+            mc_poly["scenes"]["call_ms_ranks"], mc_poly["scenes"]["value_kernels_only"] = R.rank_spread(pq_own_ms, PN, mc_poly["scenes"].get("roofline"), work=p_total)
+            mc_poly["scenes"]["call_ms_note"] = "host wall time of each rank's own synchronous c2d_mc_poly_scenes call (the call returns the totals, so there is no event pair)"
             mc_poly_scenes_keep = (pp_tab, ps_tab, p_scn, p_rob9, d_ph.get(), d_pu.get(), rank * PN)
             for a_ in (d_pp, d_ps, d_pscn, d_ph, d_pu):
                 a_.free()
@@ -769,6 +877,8 @@ def leg_scenes(R) -> None:
                 scenes_leg["evaluated_fraction"] = c["evaluated_fraction"]
                 scenes_leg["evaluated_note"] = ("samples that reach the full evaluation (second Box-Muller pair, rotation, closed-form test; vertices and the "
                                                "SAT's own arithmetic for a thin result); recorded: %s" % c.get("evaluated_source"))
+        scenes_leg["device_loop_ms_ranks"], scenes_leg["value_kernels_only"] = R.rank_spread(loop_ms, ns, scenes_leg.get("roofline"), work=local_total)
+        scenes_leg["reduce_us"] = R.time_reduce(2, reps=10)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             scenes_keep = {"tables": (tp, ts), "scenes": d_sc.get(), "hits": t_h.cpu().numpy().view(np.uint32), "used": t_u.cpu().numpy().view(np.uint32),
                            "base": base}
@@ -781,8 +891,11 @@ def leg_scenes(R) -> None:
         torch.cuda.synchronize()
         barrier()
         f0 = time.perf_counter()
+        fe0, fe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fe0.record(stream)
         eng.mc_scenes_async(d_p, 65536, d_s, 65536, d_sc, ns, 4.07, 1.74, wl.DEFAULT_BINS, wl.DEFAULT_BIN_ACCURACY,
                             fixed_n, 11, base, t_h.data_ptr(), t_u.data_ptr(), None, stream=sh)
+        fe1.record(stream)
         with torch.cuda.stream(stream):
             fsum = torch.stack([t_h.sum(dtype=torch.int64), t_u.sum(dtype=torch.int64)])
         all_reduce_sum(fsum)
@@ -794,6 +907,9 @@ def leg_scenes(R) -> None:
         scenes_leg["fixed_samples"] = {"samples_per_point": fixed_n, "seconds": round(fel, 5), "data_points_per_s": ns * world / fel,
                                        "samples_per_s": float(fsum[1].item()) / fel, "pooled_hit_fraction": float(fsum[0].item()) / float(fsum[1].item()),
                                        "note": "every data point sampled exactly 1000 times (max_samples = 1000: one schedule step, no stop rule at work)"}
+        fixed_ms = fe0.elapsed_time(fe1)
+        scenes_leg["fixed_samples"]["device_loop_ms"] = round(fixed_ms, 4)
+        scenes_leg["fixed_samples"]["device_loop_ms_ranks"], scenes_leg["fixed_samples"]["value_kernels_only"] = R.rank_spread(fixed_ms, ns)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             scenes_fixed_hits = t_h[:2000].cpu().numpy().view(np.uint32)
             scenes_keep["fixed_hits"] = scenes_fixed_hits
@@ -852,6 +968,8 @@ def leg_poly(R) -> None:
                                  "exact_GBs": round(exact_bytes / (poly_ms * 1e-3) / 1e9, 1), "exact_frac": round(exact_bytes / (poly_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                  "traffic": None, "step_ms_distribution": step_distribution(poly_step, preps)},
                     "workload": "config5: K ~ U{3..16} convex polygons, SoA [2][16][n], true normals"}
+        _, poly_leg["value_kernels_only"] = R.rank_spread(poly_ms, npoly, poly_leg["roofline"])
+        poly_leg["reduce_us"] = R.time_reduce(1, before=poly_step, reps=10)
         c = counts.get("sat_poly.config5")
         if c and npoly == c.get("pairs"):
             lane = npoly / (poly_ms * 1e-3) * c["valu_instr_per_pair"] / 1e12
@@ -912,6 +1030,8 @@ def leg_poly(R) -> None:
                                               "the padded batch (a stable counting sort that moves every vertex once), not part of a test; results are "
                                               "returned in the padded order by c2d_poly_bins_results",
                               "parity": f"booleans equal to the padded entry point's on {same} of {npoly} pairs"}
+        _, poly_leg["binned"]["value_kernels_only"] = R.rank_spread(binned_ms, npoly, poly_leg["binned"]["roofline"])
+        poly_leg["binned"]["reduce_us"] = R.time_reduce(1, before=binned_step, reps=10)
         c = counts.get("sat_poly_binned.config5")
         if c and npoly == c.get("pairs") and args.poly_bin_granularity == 1:
             lane = npoly / (binned_ms * 1e-3) * c["valu_instr_per_pair"] / 1e12
@@ -987,7 +1107,7 @@ def cpu_baselines_and_parity(R) -> None:
             if time.perf_counter() - c0 >= budget:
                 break
         cel = time.perf_counter() - c0
-        cpu_baseline = {"value": n * reps / cel, "unit": "pair_tests/s", "cores": oracle.num_threads(), "kind": "port",
+        cpu_baseline = {"value": n * reps / cel, "unit": "pair_tests/s", "cores": oracle.num_threads(), "kind": "port", "flags": oracle.build_info(),
                         "sample": f"all {n} pairs of the workload x {reps} passes ({cel:.1f} s), OpenMP", "parity": parity["config2"]}
         del host_planes
         if mc is not None:
@@ -1008,7 +1128,7 @@ def cpu_baselines_and_parity(R) -> None:
             mc["parity"] = f"hits equal on {S} of {S} samples ({mc_hits_one_step} hits)"
             if h_at_s != mc_hits_one_step:
                 raise SystemExit(f"PARITY FAILURE: Monte-Carlo hit count over the first {S} samples: GPU {mc_hits_one_step}, CPU oracle {h_at_s}")
-            mc["cpu_baseline"] = {"value": done / cel, "unit": "samples/s", "cores": oracle.num_threads(), "kind": "port",
+            mc["cpu_baseline"] = {"value": done / cel, "unit": "samples/s", "cores": oracle.num_threads(), "kind": "port", "flags": oracle.build_info(),
                                   "sample": f"first {done} samples of the same stream ({cel:.1f} s), OpenMP", "probability": h / done,
                                   "parity": mc["parity"]}
         if mc_poly is not None:  # the polygon Monte-Carlo leg: all PS samples of one step, hit for hit, then the timed walk
@@ -1026,7 +1146,7 @@ def cpu_baselines_and_parity(R) -> None:
             mc_poly["parity"] = f"hits equal on {PS} of {PS} samples ({mc_poly_hits_one_step} hits)"
             if h_at_s != mc_poly_hits_one_step:
                 raise SystemExit(f"PARITY FAILURE: polygon Monte-Carlo hit count over the first {PS} samples: GPU {mc_poly_hits_one_step}, CPU oracle {h_at_s}")
-            mc_poly["cpu_baseline"] = {"value": done / cel, "unit": "samples/s", "cores": oracle.num_threads(), "kind": "port",
+            mc_poly["cpu_baseline"] = {"value": done / cel, "unit": "samples/s", "cores": oracle.num_threads(), "kind": "port", "flags": oracle.build_info(),
                                        "sample": f"first {done} samples of the same stream ({cel:.1f} s), OpenMP", "probability": h / done,
                                        "parity": mc_poly["parity"]}
         if mc_poly is not None and "scenes" in mc_poly:  # its adaptive dataset: the first scenes of the shard, hits and stop points, then the oracle's rate
@@ -1044,7 +1164,7 @@ def cpu_baselines_and_parity(R) -> None:
                     break
             cel = time.perf_counter() - c0
             mc_poly["scenes"]["parity"] = f"hits and sample counts equal on {chk} of {chk} scenes checked"
-            mc_poly["scenes"]["cpu_baseline"] = {"value": chk / cel, "unit": "scenes/s", "samples_per_s": smp / cel, "cores": oracle.num_threads(), "kind": "port",
+            mc_poly["scenes"]["cpu_baseline"] = {"value": chk / cel, "unit": "scenes/s", "samples_per_s": smp / cel, "cores": oracle.num_threads(), "kind": "port", "flags": oracle.build_info(),
                                                  "sample": f"first {chk} scenes of the shard ({smp} samples, {cel:.1f} s), OpenMP over scenes", "parity": mc_poly["scenes"]["parity"]}
         if poly_keep is not None:  # config 5: every boolean of the 16-row batch
             hvx, hvy, hk, hout = poly_keep
@@ -1060,7 +1180,7 @@ def cpu_baselines_and_parity(R) -> None:
                 if time.perf_counter() - c0 >= budget:
                     break
             cel = time.perf_counter() - c0
-            poly_leg["cpu_baseline"] = {"value": len(ref) * reps / cel, "unit": "pair_tests/s", "cores": oracle.num_threads(), "kind": "port",
+            poly_leg["cpu_baseline"] = {"value": len(ref) * reps / cel, "unit": "pair_tests/s", "cores": oracle.num_threads(), "kind": "port", "flags": oracle.build_info(),
                                         "sample": f"all {len(ref)} pairs of the workload x {reps} passes ({cel:.1f} s), OpenMP", "parity": poly_leg["parity"]}
             poly_keep = None
         if scenes_keep is not None:  # config 4: the oracle's adaptive loop on the first scenes of the shard, chunk by chunk
@@ -1082,7 +1202,7 @@ def cpu_baselines_and_parity(R) -> None:
             if bad:
                 raise SystemExit("PARITY FAILURE: adaptive Monte-Carlo results differ from the CPU oracle (%s)" % scenes_leg["parity"])
             scenes_leg["cpu_baseline"] = {"value": done / cel, "unit": "data_points/s", "samples_per_s": cpu_samples / cel, "cores": oracle.num_threads(),
-                                          "kind": "port", "sample": f"first {done} data points of the shard ({cpu_samples} samples, {cel:.1f} s), OpenMP over scenes",
+                                          "kind": "port", "flags": oracle.build_info(), "sample": f"first {done} data points of the shard ({cpu_samples} samples, {cel:.1f} s), OpenMP over scenes",
                                           "parity": scenes_leg["parity"]}
             if "fixed_hits" in scenes_keep:  # the fixed-samples sub-leg: its first 2000 data points against the oracle
                 fh = scenes_keep["fixed_hits"]
@@ -1107,6 +1227,7 @@ def emit(R) -> None:
             "metric": "sat_pair_tests_per_s", "value": value, "unit": "pair_tests/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "value_kernels_only": R.value_kernels_only, "reduce_us": R.reduce_us, "scaling_detail": R.scaling_detail,
             "config": {"workload": ("config2: %s random OBB pairs per GPU, 16 SoA vertex planes -> u8 booleans, single SAT overlap kernel"
                                     % ("1e7" if n == 10_000_000 else str(n))),
                        "pairs_per_gpu": n, "bytes_per_pair": BYTES_PER_PAIR, "collide_rate": round(collide_rate, 5),

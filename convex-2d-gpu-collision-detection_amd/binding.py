@@ -116,7 +116,8 @@ _SIGNATURES = {
     "c2d_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "c2d_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "c2d_ctx_destroy": (C.c_int, [C.c_void_p]),
-    "c2d_ctx_info": (C.c_int, [C.c_void_p, C.POINTER(_DeviceInfo)]),
+    "c2d_ctx_info": (C.c_int, [C.c_void_p, C.POINTER(_DeviceInfo)]),   # (the 0.4 layout: kept for old binaries, not called here)
+    "c2d_ctx_info_sized": (C.c_int, [C.c_void_p, C.POINTER(_DeviceInfo), C.c_size_t]),
     "c2d_ctx_check_async": (C.c_int, [C.c_void_p]),
     "c2d_malloc": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]),
     "c2d_free": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -341,7 +342,7 @@ class Engine:
 
     def info(self) -> dict:
         di = _DeviceInfo()
-        self._check(self.lib.c2d_ctx_info(self.h, C.byref(di)), "c2d_ctx_info")
+        self._check(self.lib.c2d_ctx_info_sized(self.h, C.byref(di), C.sizeof(di)), "c2d_ctx_info_sized")   # told how large THIS mirror of the struct is
         return {"name": di.name.decode(), "arch": di.arch.decode(), "device": di.device, "compute_units": di.compute_units,
                 "wavefront_size": di.wavefront_size, "lds_bytes_per_cu": di.lds_bytes_per_cu, "hbm_bytes": di.hbm_bytes,
                 "pci_bus_id": di.pci_bus_id.decode()}

@@ -18,8 +18,7 @@ void workspace_stamp_behind(c2d_ctx* ctx, hipStream_t s)
         return;
     }
     ctx->ws_expect[kStampOther] = ticket;
-    ctx->ws_stream = s;
-    ctx->ws_outstanding = true;
+    workspace_tickets_on(ctx, s);
 }
 
 }  // namespace c2d
@@ -106,25 +105,30 @@ int c2d_ctx_destroy(c2d_ctx* ctx)
     return C2D_OK;
 }
 
-int c2d_ctx_info(const c2d_ctx* ctx, c2d_device_info* out)
+int c2d_ctx_info_sized(const c2d_ctx* ctx, c2d_device_info* out, size_t out_bytes)
 {
-    if (!ctx || !out) return C2D_ERR_INVALID_ARG;
-    std::memset(out, 0, sizeof *out);
+    if (!ctx || !out || out_bytes == 0) return C2D_ERR_INVALID_ARG;
+    c2d_device_info di;
+    std::memset(&di, 0, sizeof di);
     // (some boxes of the pool report an empty marketing name: the architecture then stands in for it)
-    if (ctx->prop.name[0]) std::snprintf(out->name, sizeof out->name, "%s", ctx->prop.name);
-    else std::snprintf(out->name, sizeof out->name, "gfx950 device (the runtime reports no marketing name)");
-    std::snprintf(out->arch, sizeof out->arch, "%s", ctx->prop.gcnArchName);
-    out->device = ctx->device;
-    out->compute_units = ctx->prop.multiProcessorCount;
-    out->wavefront_size = ctx->prop.warpSize;
-    out->lds_bytes_per_cu = (int)ctx->prop.maxSharedMemoryPerMultiProcessor;
-    out->hbm_bytes = ctx->prop.totalGlobalMem;
-    if (hipDeviceGetPCIBusId(out->pci_bus_id, (int)sizeof out->pci_bus_id, ctx->device) != hipSuccess) {
+    if (ctx->prop.name[0]) std::snprintf(di.name, sizeof di.name, "%s", ctx->prop.name);
+    else std::snprintf(di.name, sizeof di.name, "gfx950 device (the runtime reports no marketing name)");
+    std::snprintf(di.arch, sizeof di.arch, "%s", ctx->prop.gcnArchName);
+    di.device = ctx->device;
+    di.compute_units = ctx->prop.multiProcessorCount;
+    di.wavefront_size = ctx->prop.warpSize;
+    di.lds_bytes_per_cu = (int)ctx->prop.maxSharedMemoryPerMultiProcessor;
+    di.hbm_bytes = ctx->prop.totalGlobalMem;
+    if (hipDeviceGetPCIBusId(di.pci_bus_id, (int)sizeof di.pci_bus_id, ctx->device) != hipSuccess) {
         (void)hipGetLastError();
-        out->pci_bus_id[0] = 0;
+        di.pci_bus_id[0] = 0;
     }
+    std::memcpy(out, &di, out_bytes < sizeof di ? out_bytes : sizeof di);   // never past the caller's struct
     return C2D_OK;
 }
+
+// the exported symbol of the 0.4 layout (include/c2d.h): for binaries built before the struct grew
+int (c2d_ctx_info)(const c2d_ctx* ctx, c2d_device_info* out) { return c2d_ctx_info_sized(ctx, out, C2D_DEVICE_INFO_BYTES_0_4); }
 
 int c2d_malloc(c2d_ctx* ctx, void** d_ptr, size_t bytes)
 {

@@ -37,8 +37,12 @@ struct c2d_ctx {
     uint32_t* d_async_err = nullptr;           // device address of the same word
     // Guard of the shared workspace (count words, adaptive state, survivor lists, scratch): see workspace_acquire below.
     // ws_stream is only ever COMPARED with the stream of the next call, never handed to the runtime: the caller may have
-    // destroyed it.
+    // destroyed it — and the runtime may then hand the SAME ADDRESS to the next stream it creates (profiles/r05_stream_lifetime_probe.txt,
+    // cases 2 and 4), so the pointer alone does not say "the same stream": ws_stream_id is hipStreamGetId of the stream at the moment
+    // the tickets were issued (a number the runtime never gives twice), compared with the id of the LIVE stream of the next call.
     hipStream_t ws_stream = nullptr;
+    unsigned long long ws_stream_id = 0;
+    bool ws_ticket_pending = false;                 // a ticket was taken for a launch whose launch check has not run yet (C2D_LAUNCH_CHECK)
     bool ws_outstanding = false;                    // tickets were issued (on ws_stream) that no check has seen retired yet
     unsigned ws_ticket = 0;                         // the last ticket handed out (32 bits: workspace_next_ticket handles the wrap)
     unsigned ws_expect[c2d::kStampSlots] = {};      // per stamp: the ticket it must have reached
@@ -74,11 +78,17 @@ inline int fail_arg(const c2d_ctx* ctx, const char* msg)
         if (e__ != hipSuccess) return c2d::fail_hip(ctx, e__, #call, __FILE__, __LINE__); \
     } while (0)
 
-// Launch-error check that does not synchronise (graph-capture safe).
+// Launch-error check that does not synchronise (graph-capture safe).  A launch that took a workspace ticket and then failed has
+// no wave that will ever raise the stamps to it: the ticket is taken back (workspace_launch_failed below), or every later call
+// on another stream would be refused until the caller synchronised a stream it may no longer have.
 #define C2D_LAUNCH_CHECK(ctx)                                                     \
     do {                                                                          \
         hipError_t e__ = hipGetLastError();                                       \
-        if (e__ != hipSuccess) return c2d::fail_hip(ctx, e__, "kernel launch", __FILE__, __LINE__); \
+        if (e__ != hipSuccess) {                                                  \
+            c2d::workspace_launch_failed(ctx);                                    \
+            return c2d::fail_hip(ctx, e__, "kernel launch", __FILE__, __LINE__);  \
+        }                                                                         \
+        c2d::workspace_launch_ok(ctx);                                            \
     } while (0)
 
 struct DeviceGuard {
@@ -120,9 +130,22 @@ inline bool stream_is_capturing(hipStream_t s)
     return st != hipStreamCaptureStatusNone;
 }
 
+// What the runtime calls the LIVE stream `s` (the caller is about to launch on it): a number it gives once, to one stream.
+// kUnknownStreamId when it will not say — then identity cannot be proven and the guard checks the stamps instead.
+constexpr unsigned long long kUnknownStreamId = ~0ull;
+inline unsigned long long stream_identity(hipStream_t s)
+{
+    unsigned long long id = 0;
+    if (hipStreamGetId(s, &id) != hipSuccess) { (void)hipGetLastError(); return kUnknownStreamId; }
+    return id;
+}
+
 inline int workspace_acquire(c2d_ctx* ctx, hipStream_t s, bool uses)
 {
-    if (!uses || !ctx->ws_outstanding || ctx->ws_stream == s) return C2D_OK;
+    if (!uses || !ctx->ws_outstanding) return C2D_OK;
+    // the same stream as the outstanding tickets': the stream orders the calls.  The same ADDRESS is not enough — a stream destroyed
+    // with work in flight and a new one created in its place are two streams.
+    if (ctx->ws_stream == s && ctx->ws_stream_id != kUnknownStreamId && stream_identity(s) == ctx->ws_stream_id) return C2D_OK;
     if (stream_is_capturing(s)) return C2D_OK;
     if (!ctx->ws_probe_stream) {
         hipError_t e = hipStreamCreateWithFlags(&ctx->ws_probe_stream, hipStreamNonBlocking);
@@ -166,6 +189,15 @@ inline unsigned workspace_next_ticket(c2d_ctx* ctx)
     return ++ctx->ws_ticket;
 }
 
+// tickets are outstanding on the live stream `s` from now on (the id is asked for only when the stream changes: `s` == ws_stream with
+// tickets outstanding has passed workspace_acquire's identity check in this very call)
+inline void workspace_tickets_on(c2d_ctx* ctx, hipStream_t s)
+{
+    if (!ctx->ws_outstanding || ctx->ws_stream != s) ctx->ws_stream_id = stream_identity(s);
+    ctx->ws_stream = s;
+    ctx->ws_outstanding = true;
+}
+
 // the ticket of one launch whose waves count through the single-level words / the two-level words; call it right before the
 // launch on stream `s` with the launch's number of waves
 inline CountWs workspace_count_ticket(c2d_ctx* ctx, hipStream_t s, size_t n_waves, bool counted)
@@ -175,8 +207,8 @@ inline CountWs workspace_count_ticket(c2d_ctx* ctx, hipStream_t s, size_t n_wave
     ws.ticket = workspace_next_ticket(ctx);
     const size_t used = n_waves < kCountWords ? n_waves : kCountWords;
     for (size_t i = 0; i < used; i++) ctx->ws_expect[i] = ws.ticket;
-    ctx->ws_stream = s;
-    ctx->ws_outstanding = true;
+    workspace_tickets_on(ctx, s);
+    ctx->ws_ticket_pending = true;
     return ws;
 }
 
@@ -188,8 +220,8 @@ inline CountWs workspace_count_ticket2(c2d_ctx* ctx, hipStream_t s, size_t n_wav
     size_t used = n_waves < kCountWords1 ? n_waves : kCountWords1;
     used = used < kCountWords2 ? used : kCountWords2;
     for (size_t i = 0; i < used; i++) ctx->ws_expect[kCountWords + i] = ws.ticket;
-    ctx->ws_stream = s;
-    ctx->ws_outstanding = true;
+    workspace_tickets_on(ctx, s);
+    ctx->ws_ticket_pending = true;
     return ws;
 }
 
@@ -219,8 +251,24 @@ struct WorkspaceUse {
 // `s` has been synchronised by the caller: if it is the stream the outstanding tickets were issued on, they have retired.
 inline void workspace_stream_drained(c2d_ctx* ctx, hipStream_t s)
 {
-    if (ctx->ws_outstanding && ctx->ws_stream == s) ctx->ws_outstanding = false;
+    if (ctx->ws_outstanding && ctx->ws_stream == s && stream_identity(s) == ctx->ws_stream_id && ctx->ws_stream_id != kUnknownStreamId)
+        ctx->ws_outstanding = false;
 }
+
+// C2D_LAUNCH_CHECK's two ways out.  After a failed launch that had taken a ticket nothing will raise the stamps to it.  ws_stream is
+// the stream of the failing call (the ticket set it), hence live: drain it — every ticket outstanding on the ctx was issued on
+// it, a change of stream is only ever accepted with nothing outstanding — and start again with no expectations.
+inline void workspace_launch_ok(c2d_ctx* ctx) { ctx->ws_ticket_pending = false; }
+inline void workspace_launch_failed(c2d_ctx* ctx)
+{
+    if (!ctx->ws_ticket_pending) return;
+    ctx->ws_ticket_pending = false;
+    if (hipStreamSynchronize(ctx->ws_stream) != hipSuccess) { (void)hipGetLastError(); return; }   // (cannot prove anything retired: stay guarded)
+    std::memset(ctx->ws_expect, 0, sizeof ctx->ws_expect);
+    ctx->ws_outstanding = false;
+}
+inline void workspace_launch_ok(const c2d_ctx*) {}       // (entry points that hold the ctx const take no tickets)
+inline void workspace_launch_failed(const c2d_ctx*) {}
 
 inline int grid_for(size_t work_items, int block, int max_blocks)
 {

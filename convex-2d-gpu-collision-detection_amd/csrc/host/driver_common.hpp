@@ -5,6 +5,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cctype>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -19,6 +20,18 @@
 #include "../../../include/c2d.h"
 #include "cli.hpp"
 #include "npy.hpp"
+
+// a string as the inside of a JSON string literal (a path from dladdr may hold quotes, backslashes or control characters)
+inline std::string json_escape(const std::string& in)
+{
+    std::string out;
+    for (const unsigned char c : in) {
+        if (c == '"' || c == '\\') { out += '\\'; out += static_cast<char>(c); }
+        else if (c < 0x20) { char b[8]; std::snprintf(b, sizeof b, "\\u%04x", c); out += b; }
+        else out += static_cast<char>(c);
+    }
+    return out;
+}
 
 namespace fs = std::filesystem;
 
@@ -97,7 +110,8 @@ inline Shard resolve_shard(const cli::Parser& p)
 inline void add_shard_options(cli::Parser& p)
 {
     using K = cli::Option;
-    p.add("gpus", 0, K::VALUE, "use N GPUs of this node: the driver starts one process per GPU itself and prints one aggregated summary");
+    p.add("gpus", 0, K::VALUE, "use N GPUs of this node: the driver starts one process per GPU itself and prints one aggregated summary "
+                               "(refused under a preloaded profiler: profile ONE rank, --rank k --world_size N --dist_id_file F, never the launcher)");
     p.add("rank", 0, K::VALUE, "this process' shard index (default: $RANK or 0)");
     p.add("world_size", 0, K::VALUE, "number of shards = GPUs (default: $WORLD_SIZE or 1)");
     p.add("device", 0, K::VALUE, "GPU index (default: $LOCAL_RANK or rank)");
@@ -337,7 +351,7 @@ inline int print_json_summary(const char* tool, const Shard& sh, RunStats st, in
     int ranks = 1;
     std::string rccl_json;
     if (link && link->active()) {
-        rccl_json = ", \"rccl_version\": " + std::to_string(link->rccl_version) + ", \"rccl_library\": \"" + link->rccl_library + "\"";
+        rccl_json = ", \"rccl_version\": " + std::to_string(link->rccl_version) + ", \"rccl_library\": \"" + json_escape(link->rccl_library) + "\"";
         unsigned long long w[9] = {st.samples, st.hits, st.scenes, st.cp_hist[0], st.cp_hist[1], st.cp_hist[2], st.cp_hist[3],
                                    static_cast<unsigned long long>(batches), 1ull};
         int rc = link->sum(w, 9, stream);
@@ -371,8 +385,36 @@ inline int print_json_summary(const char* tool, const Shard& sh, RunStats st, in
 #include <sys/wait.h>
 #include <unistd.h>
 
+// --gpus N starts the ranks by fork + execv of this very program.  That is only safe while THIS process has not initialised the GPU
+// — it has not: the launcher never calls into libc2d — but a profiler or tool library preloaded into it (rocprofv3 and friends
+// put theirs into every process they start) has done so before main, and an exec from a process that holds the GPU is what this
+// pool's hosts forbid: it can take the machine down.  So: which preloaded tool would make the self-launch unsafe, or nullptr.
+inline const char* preloaded_gpu_tool(std::string* what)
+{
+    static const char* const vars[] = {"ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_LIBRARY", "LD_PRELOAD"};
+    static const char* const names[] = {"rocprof", "roctracer", "roctx", "rocprofiler", "librocm-debug", "libhsa", "libamdhip"};
+    for (const char* v : vars) {
+        const char* val = std::getenv(v);
+        if (!val || !*val) continue;
+        if (std::string(v) != "LD_PRELOAD") { *what = std::string(v) + "=" + val; return v; }   // a tool library is loaded into the HSA runtime
+        std::string low(val);
+        for (auto& c : low) c = static_cast<char>(std::tolower(static_cast<unsigned char>(c)));
+        for (const char* nm : names)
+            if (low.find(nm) != std::string::npos) { *what = std::string(v) + "=" + val; return v; }
+    }
+    return nullptr;
+}
+
 inline int launch_ranks(int n, int argc, char** argv, const std::vector<std::string>& extra)
 {
+    std::string tool;
+    if (preloaded_gpu_tool(&tool)) {
+        std::fprintf(stderr, "error: --gpus %d refused: a profiler / tool library is preloaded into this process (%s).  The launcher starts its "
+                             "ranks by execv, which is only safe from a process that has not initialised the GPU, and a preloaded tool has.  "
+                             "Profile ONE rank instead: start the ranks by hand (--rank k --world_size %d --dist_id_file FILE on each, RANK / "
+                             "WORLD_SIZE / LOCAL_RANK work too) and put the profiler in front of one of them.\n", n, tool.c_str(), n);
+        return EXIT_FAILURE;
+    }
     std::vector<std::string> args;
     for (int i = 0; i < argc; i++) {
         const std::string a = argv[i];

@@ -60,7 +60,7 @@ extern "C" {
 #endif
 
 #define C2D_VERSION_MAJOR 0
-#define C2D_VERSION_MINOR 5
+#define C2D_VERSION_MINOR 6
 
 /* ---- status codes ------------------------------------------------------ */
 #define C2D_OK 0
@@ -102,7 +102,16 @@ int c2d_device_count(int* count);
  * (compute_collision_probability.cu:212-251). */
 int c2d_ctx_create(int device, c2d_ctx** out);
 int c2d_ctx_destroy(c2d_ctx* ctx);
+/* c2d_device_info may grow at its end (0.5 added pci_bus_id), so it is filled through a call that is told how large the
+ * CALLER's struct is: c2d_ctx_info_sized writes the first min(out_bytes, sizeof(c2d_device_info)) bytes of the current layout
+ * and nothing beyond out_bytes.  Sources compiled against this header get it through the c2d_ctx_info macro below, with the
+ * size of the struct they were compiled with.  The EXPORTED symbol c2d_ctx_info stays for binaries built against the 0.4
+ * header, which declared the struct without pci_bus_id: it writes that layout only (C2D_DEVICE_INFO_BYTES_0_4 bytes: everything
+ * up to and including hbm_bytes), never past the end of an old caller's struct. */
+#define C2D_DEVICE_INFO_BYTES_0_4 (offsetof(c2d_device_info, hbm_bytes) + sizeof(size_t))
 int c2d_ctx_info(const c2d_ctx* ctx, c2d_device_info* out);
+int c2d_ctx_info_sized(const c2d_ctx* ctx, c2d_device_info* out, size_t out_bytes);
+#define c2d_ctx_info(ctx, out) c2d_ctx_info_sized((ctx), (out), sizeof(c2d_device_info))
 /* Argument errors that only the device can see (today: a polygon vertex count outside
  * 1..C2D_POLY_KMAX) are reported asynchronously: the kernel records them in a pinned word
  * of the ctx and the first c2d_stream_synchronize — or this call, for callers that
@@ -416,7 +425,9 @@ int c2d_sample_scenes(c2d_ctx* ctx, const Pose* d_poses, uint32_t num_poses,
  * c2d_mc_scenes, with the same random stream, draw order, sample sharding and stopping rule.
  * STATUS: c2d_mc_poly_* goes beyond the reference — the semantics below (notably "dw, dh scale the
  * obstacle frame") are this build's own generalisation, pinned only by this build's own oracle and by
- * the rectangle case; no reference code or fixture stands behind them.
+ * the rectangle case; no reference code or fixture stands behind them.  They are an extension OUTSIDE
+ * BASELINE.json's configs (none of the five names a polygon Monte-Carlo), frozen as of round 5: kept
+ * working and tested, not developed further.
  *
  *   robot     a polygon in its own frame, rotated by theta and moved to pos with the arithmetic of
  *             rot_trans_rectangle (utils.cu:132-142; ccp.cu:132-133);

@@ -59,6 +59,21 @@ static inline float dot2(float a, float x, float b, float y)
 }
 int c2d_oracle_fmad_variant(void) { return C2D_ORACLE_FMAD; }
 
+/* compiler and flags this library was built with (oracle/Makefile passes its flags): bench.py's cpu_baseline quotes them */
+#ifndef C2D_ORACLE_CFLAGS
+#define C2D_ORACLE_CFLAGS "(flags not recorded: built outside oracle/Makefile)"
+#endif
+const char* c2d_oracle_build_info(void)
+{
+#if defined(__clang__)
+    return "clang " __VERSION__ " " C2D_ORACLE_CFLAGS;
+#elif defined(__GNUC__)
+    return "gcc " __VERSION__ " " C2D_ORACLE_CFLAGS;
+#else
+    return "cc " C2D_ORACLE_CFLAGS;
+#endif
+}
+
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 

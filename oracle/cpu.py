@@ -79,6 +79,7 @@ def lib() -> C.CDLL:
         L = C.CDLL(_LIB_PATH)
         fp = C.POINTER(C.c_float)
         L.c2d_oracle_num_threads.restype = C.c_int
+        L.c2d_oracle_build_info.restype = C.c_char_p
         L.c2d_oracle_logf.restype = C.c_float
         L.c2d_oracle_logf.argtypes = [C.c_float]
         L.c2d_oracle_sincosf.argtypes = [C.c_float, fp, fp]
@@ -113,6 +114,11 @@ def _f32(a):
 
 def _ptr(a, ct=C.c_float):
     return a.ctypes.data_as(C.POINTER(ct))
+
+
+def build_info() -> str:
+    """Compiler and flags of the loaded library (oracle/Makefile), for bench.py's cpu_baseline line."""
+    return lib().c2d_oracle_build_info().decode()
 
 
 def num_threads() -> int:

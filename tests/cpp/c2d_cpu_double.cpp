@@ -132,15 +132,19 @@ int c2d_ctx_create(int device, c2d_ctx** out)
 
 int c2d_ctx_destroy(c2d_ctx* ctx) { delete ctx; return C2D_OK; }
 
-int c2d_ctx_info(const c2d_ctx* ctx, c2d_device_info* out)
+int c2d_ctx_info_sized(const c2d_ctx* ctx, c2d_device_info* out, size_t out_bytes)
 {
-    if (!ctx || !out) return C2D_ERR_INVALID_ARG;
-    std::memset(out, 0, sizeof *out);
-    std::snprintf(out->name, sizeof out->name, "cpu double (tests only)");
-    std::snprintf(out->arch, sizeof out->arch, "none");
-    out->device = ctx->device;
+    if (!ctx || !out || out_bytes == 0) return C2D_ERR_INVALID_ARG;
+    c2d_device_info di;
+    std::memset(&di, 0, sizeof di);
+    std::snprintf(di.name, sizeof di.name, "cpu double (tests only)");
+    std::snprintf(di.arch, sizeof di.arch, "none");
+    di.device = ctx->device;
+    std::memcpy(out, &di, out_bytes < sizeof di ? out_bytes : sizeof di);
     return C2D_OK;
 }
+
+int (c2d_ctx_info)(const c2d_ctx* ctx, c2d_device_info* out) { return c2d_ctx_info_sized(ctx, out, C2D_DEVICE_INFO_BYTES_0_4); }
 
 int c2d_malloc(c2d_ctx* ctx, void** p, size_t bytes)
 {

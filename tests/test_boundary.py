@@ -45,7 +45,7 @@ def test_struct_layouts_match_reference_sizes(pkg):
 
 def test_version_and_status_strings(pkg):
     lib = pkg.load_library()
-    assert lib.c2d_version() == 5   # 0.5: round 5 added c2d_dist_rccl_version and c2d_device_info.pci_bus_id (0.4: c2d_mc_poly_*, c2d_sat_rect_pairs_*_host, c2d_uniform_table_minstd, c2d_sqrt_f32, c2d_dist_stream_synchronize)
+    assert lib.c2d_version() == 6   # 0.6: round 6 added c2d_ctx_info_sized (c2d_ctx_info the symbol writes the 0.4 layout only); 0.5: round 5 added c2d_dist_rccl_version and c2d_device_info.pci_bus_id (0.4: c2d_mc_poly_*, c2d_sat_rect_pairs_*_host, c2d_uniform_table_minstd, c2d_sqrt_f32, c2d_dist_stream_synchronize)
     assert lib.c2d_status_string(0) == b"ok"
     for st in (-1, -2, -3, -4, -5, -6):
         assert lib.c2d_status_string(st) not in (b"ok", b"unknown status")

@@ -86,6 +86,24 @@ def test_multi_rank_flags_are_checked_before_any_gpu_work(tmp_path):
     assert "--gpus" in run([GEN, "--help"]).stdout and "--pair_samples" in run([CCP, "--help"]).stdout
 
 
+def test_self_launch_is_refused_under_a_preloaded_profiler(tmp_path):
+    """--gpus N starts the ranks by fork + execv of the driver itself: safe only from a process that has not initialised the GPU.
+    A profiler / tool library preloaded into the launcher (rocprofv3 puts its own into every process it starts) has done that
+    before main, and an exec from such a process is what the pool's hosts forbid.  The launcher refuses, names the variable and
+    says what to do instead (profile one rank); nothing is started, no id file is left.  A single rank is not affected."""
+    for var, val in (("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so"), ("HSA_TOOLS_LIB", "libanything.so"),
+                     ("LD_PRELOAD", "/nonexistent/libRocProfiler-sdk-tool.so.1")):
+        env = dict(os.environ, TMPDIR=str(tmp_path))
+        env[var] = val
+        for cmd in ([GEN, "--data_dir", str(tmp_path / "d"), "--gpus", "2", "-n", "2", "-b", "10"], [CCP, "--pair_samples", "1000", "--gpus", "3"]):
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=60, env=env)
+            assert out.returncode != 0 and "refused" in out.stderr and var in out.stderr and "--rank k --world_size" in out.stderr, out.stderr
+            assert "no usable device" not in out.stderr and "execv" not in out.stderr.replace("by execv", "")   # no rank was started
+        assert not list(tmp_path.glob("c2d_dist_id_*")) and not (tmp_path / "d").exists()
+    # an unrelated preload does not trigger it (the ranks start and, on this box, fail for want of a GPU or run)
+    assert "--gpus" in run([GEN, "--help"]).stdout and "never the launcher" in run([GEN, "--help"]).stdout
+
+
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="CPU-only behaviour")
 def test_self_launched_ranks_propagate_failure_without_gpu(tmp_path):
     """--gpus N: the launcher starts N fresh copies of itself and returns the first non-zero exit status; without a GPU every

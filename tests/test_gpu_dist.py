@@ -222,6 +222,25 @@ def test_bench_with_four_ranks_sharing_the_device(tmp_path):
     assert j["config"]["rccl_version"] == 0 and j["config"]["rccl_library"] == "file (rehearsal)" and j["config"]["torch_backend"] == "gloo"
     for r in range(N):  # every rank said which card it sits on
         assert f"[bench] rank {r} of {N}: device 0" in out.stderr, out.stderr[-3000:]
+    # what makes the N > 1 line readable: every rank's own kernel time, the closing reduce by itself, and the rate of
+    # the kernels alone beside `value`, in every leg that closes with the reduce
+    spreads = [j["roofline"]["kernel_ms_ranks"], j["mc"]["kernel_ms_ranks"], j["scenes"]["device_loop_ms_ranks"],
+               j["scenes"]["fixed_samples"]["device_loop_ms_ranks"], j["poly"]["roofline"]["kernel_ms_ranks"],
+               j["poly"]["binned"]["roofline"]["kernel_ms_ranks"]]
+    for sp in spreads:
+        assert sp["ranks"] == N and sp["max"] >= sp["median"] >= sp["min"] > 0 and 0 <= sp["slowest_rank"] < N, sp
+    for leg in (j, j["mc"], j["scenes"], j["poly"], j["poly"]["binned"]):
+        assert leg["value_kernels_only"] > 0, leg.get("metric")
+        ru = leg["reduce_us"]
+        assert ru["reps"] > 0 and ru["event_max"] >= ru["event_median"] >= ru["event_min"] >= 0 and ru["host_median"] > 0, ru
+    assert j["scenes"]["fixed_samples"]["value_kernels_only"] > 0
+    # the kernels alone are never slower than the region that contains them, and the region's remainder is stated
+    assert j["value_kernels_only"] >= j["value"] * 0.999
+    sd = j["scaling_detail"]
+    assert sd["barrier_us"] > 0 and abs(sd["timed_region_ms"] - j["ms_per_step"] * j["steps"]) < 1e-3
+    assert abs(sd["timed_region_minus_kernels_us"] - (sd["timed_region_ms"] - sd["kernels_ms_slowest_rank"]) * 1e3) < 1.0
+    for rf in (j["roofline"], j["poly"]["roofline"], j["poly"]["binned"]["roofline"]):
+        assert 0 < rf["frac_slowest_rank"] <= rf["frac"] * 1.0001, rf
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mc-samples", str(N * 1000000), "--scenes", str(N * 10000)] + small,
                          capture_output=True, text=True, timeout=900, env=env)
     assert one.returncode == 0, one.stderr[-3000:]

@@ -193,3 +193,33 @@ def test_sample_stream_outputs(eng, n, begin):
         a.free()
     plain_n.free()
     plain_r.free()
+
+
+def test_device_info_never_writes_past_the_callers_struct(eng, pkg):
+    """c2d_device_info grew at its end in 0.5 (pci_bus_id) and c2d_ctx_info cleared sizeof(the NEW struct) bytes of the
+    caller's: a binary built against the 0.4 header was overrun by 32 bytes.  Since 0.6 the struct is filled through
+    c2d_ctx_info_sized, which is told the caller's size; the exported symbol c2d_ctx_info writes the 0.4 layout only."""
+    import ctypes as C
+
+    full = 128 + 64 + 4 * 4 + 8 + 32            # include/c2d.h: name, arch, four ints, hbm_bytes, pci_bus_id
+    old = full - 32                             # C2D_DEVICE_INFO_BYTES_0_4
+    lib = eng.lib
+    ref = eng.info()
+    assert C.sizeof(pkg.binding._DeviceInfo) == full
+    for size in (1, 100, 128, old, old + 1, full - 1, full, full + 64):
+        buf = (C.c_ubyte * (full + 256))(*([0xA5] * (full + 256)))
+        rc = lib.c2d_ctx_info_sized(eng.h, C.cast(buf, C.POINTER(pkg.binding._DeviceInfo)), C.c_size_t(size))
+        assert rc == 0
+        raw = bytes(buf)
+        wrote = min(size, full)
+        assert set(raw[wrote:]) == {0xA5}, size                      # nothing beyond the caller's size (nor beyond the struct's)
+        assert raw[:min(wrote, len(ref["name"]))] == ref["name"].encode()[:min(wrote, len(ref["name"]))]
+        if size >= full:
+            assert raw[old:full].split(b"\0")[0].decode() == ref["pci_bus_id"]
+    # the exported symbol of the 0.4 header: the old layout, not one byte more
+    buf = (C.c_ubyte * (full + 256))(*([0xA5] * (full + 256)))
+    assert lib.c2d_ctx_info(eng.h, C.cast(buf, C.POINTER(pkg.binding._DeviceInfo))) == 0
+    raw = bytes(buf)
+    assert set(raw[old:]) == {0xA5} and raw[:old].split(b"\0")[0].decode() == ref["name"]
+    assert int.from_bytes(raw[old - 8:old], "little") == ref["hbm_bytes"]
+    assert lib.c2d_ctx_info_sized(eng.h, C.cast(buf, C.POINTER(pkg.binding._DeviceInfo)), C.c_size_t(0)) == -1

@@ -17,7 +17,8 @@ wl = importlib.import_module("c2d_amd.workloads")
 from oracle import cpu as oracle  # noqa: E402
 
 
-def one(eng, rng, idx):
+def one(eng, rng, idx, announce=None):
+    """One configuration; `announce(text)` is called with its description BEFORE any GPU work, so that a fault names its input."""
     ntab = int(rng.integers(1, 200))
     tp, ts, _ = wl.random_tables(ntab, ntab, seed=int(rng.integers(1 << 30)), shape_variance=bool(rng.integers(2)))
     if rng.random() < 0.2:  # some zero standard deviations (deterministic scenes)
@@ -43,6 +44,9 @@ def one(eng, rng, idx):
     nb = int(rng.integers(2, 6))
     bins = np.concatenate([[0.0], np.sort(rng.uniform(0.001, 0.9, nb - 2)), [1.0]]).astype(np.float32)
     acc = np.sort(rng.uniform(5e-4, 5e-2, nb - 1)).astype(np.float32)
+    if announce is not None:
+        announce(f"config {idx}: scenes {ns} tables {ntab} robot {rw!r} x {rh!r} spread {spread!r} schedule {schedule} max_samples {max_samples} "
+                 f"bins {bins.tolist()} accuracy {acc.tolist()} seed {seed} base {base}")
     scenes = oracle.sample_scenes(tp, ts, rw, rh, spread, seed, base, ns)
     h_ref, u_ref, rows_ref, tot_ref = oracle.mc_scenes(tp, ts, scenes, rw, rh, bins, acc, max_samples, seed + 1, base, schedule=schedule)
     d_p, d_s = eng.to_device(tp), eng.to_device(ts)
@@ -58,6 +62,8 @@ def one(eng, rng, idx):
     begin, count = int(rng.integers(1 << 34)), int(rng.integers(1, 200_000))
     pose, sd = tuple(float(v) for v in tp[pi]), tuple(float(v) for v in ts[vi])
     pos = (float(scenes["x"][j]), float(scenes["y"][j]))
+    if announce is not None:
+        announce(f"config {idx}: mc_pair scene {j} of it, samples [{begin}, {begin + count})")
     d_hits = eng.zeros(1, np.uint64)
     eng.mc_pair(rw, rh, pos, pose, sd, seed, base + j, begin, count, d_hits)
     ok = ok and int(d_hits.get()[0]) == oracle.mc_pair(rw, rh, pos, pose, sd, seed, base + j, begin, count)

@@ -17,13 +17,17 @@ wl = importlib.import_module("c2d_amd.workloads")
 from oracle import cpu as oracle  # noqa: E402
 
 
-def one(eng, rng, idx):
+def one(eng, rng, idx, announce=None):
+    """One configuration; `announce(text)` is called with its description BEFORE any GPU work, so that a fault names its input."""
     rows = int(rng.integers(1, 17))
     kmax = int(rng.integers(1, rows + 1))
     kmin = int(rng.integers(1, kmax + 1))
     n = int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, int(rng.integers(1, 5000)), int(rng.integers(5000, 300_000))]))
     extent = float(rng.choice([0.2, 0.5, 1.0, 2.0, 4.0, 8.0]))
-    vx, vy, k = wl.random_convex_polygons(n, seed=int(rng.integers(1 << 30)), kmin=kmin, kmax=kmax, extent=extent, rows=rows)
+    pseed = int(rng.integers(1 << 30))
+    if announce is not None:
+        announce(f"config {idx}: sat_poly_pairs_rows n {n} rows {rows} k {kmin}..{kmax} extent {extent} polygon seed {pseed}")
+    vx, vy, k = wl.random_convex_polygons(n, seed=pseed, kmin=kmin, kmax=kmax, extent=extent, rows=rows)
     # reverse the orientation of a random subset
     for p in range(2):
         flip = np.flatnonzero(rng.random(n) < 0.3)

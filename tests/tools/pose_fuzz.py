@@ -43,28 +43,37 @@ def make(rng, n):
     return p, (["random", "random", "random", "random", "non-finite"][kind], scale, offset, ext, lo, hi)
 
 
+def one(eng, rng, idx, announce=None):
+    """One configuration; `announce(text)` is called with its description BEFORE any GPU work, so that a fault names its input."""
+    n = int(rng.choice([1, 255, 256, 257, 100_003, 400_000]))
+    poses, what = make(rng, n)
+    off = int(rng.integers(0, 2))
+    if announce is not None:
+        announce(f"config {idx}: sat_rect_pairs_pose n {n} plane offset {off} floats, {what}")
+    ref, ref_cnt = oracle.sat_rect_pairs_pose(poses)
+    host = np.zeros((10, n + 4), np.float32)
+    host[:, off:off + n] = poses
+    d = eng.to_device(host)
+    d_out, d_cnt = eng.zeros(n, np.uint8), eng.zeros(1, np.uint64)
+    eng.sat_rect_pairs_pose([d.row(k) + 4 * off for k in range(10)], n, d_out, d_cnt)
+    bad = int((d_out.get() != ref).sum())
+    ok = not bad and int(d_cnt.get()[0]) == ref_cnt
+    if not ok:
+        print(f"MISMATCH config {idx}: {what} n {n} offset {off}: {bad} booleans differ", flush=True)
+    for a in (d, d_out, d_cnt):
+        a.free()
+    return ok, (what[0], n, off)
+
+
 def main():
     configs = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
     eng = pkg.Engine(0)
     fails, pairs = 0, 0
     for i in range(configs):
-        n = int(rng.choice([1, 255, 256, 257, 100_003, 400_000]))
-        poses, what = make(rng, n)
-        ref, ref_cnt = oracle.sat_rect_pairs_pose(poses)
-        off = int(rng.integers(0, 2))
-        host = np.zeros((10, n + 4), np.float32)
-        host[:, off:off + n] = poses
-        d = eng.to_device(host)
-        d_out, d_cnt = eng.zeros(n, np.uint8), eng.zeros(1, np.uint64)
-        eng.sat_rect_pairs_pose([d.row(k) + 4 * off for k in range(10)], n, d_out, d_cnt)
-        bad = int((d_out.get() != ref).sum())
-        if bad or int(d_cnt.get()[0]) != ref_cnt:
-            fails += 1
-            print(f"MISMATCH config {i}: {what} n {n} offset {off}: {bad} booleans differ", flush=True)
-        pairs += n
-        for a in (d, d_out, d_cnt):
-            a.free()
+        ok, info = one(eng, rng, i)
+        fails += not ok
+        pairs += info[1]
         if (i + 1) % 50 == 0:
             print(f"  {i + 1} / {configs} configurations, {pairs} pairs, {fails} failures so far", flush=True)
     print(f"pose fuzz: {configs} configurations, {pairs} pairs, {fails} failures")
