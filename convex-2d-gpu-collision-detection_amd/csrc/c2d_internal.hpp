@@ -1,6 +1,7 @@
 // c2d_internal.hpp — context object and error plumbing shared by the C-ABI files.
 #pragma once
 
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -131,13 +132,44 @@ inline bool stream_is_capturing(hipStream_t s)
 }
 
 // What the runtime calls the LIVE stream `s` (the caller is about to launch on it): a number it gives once, to one stream.
-// kUnknownStreamId when it will not say — then identity cannot be proven and the guard checks the stamps instead.
+// hipStreamGetId exists since HIP 7.1 and is looked up in the libamdhip64 this process already holds, not linked: a PyTorch process
+// has loaded PyTorch's own libamdhip64.so.7 (HIP 7.0 in this image) before libc2d.so, and a library that NEEDS the symbol does not
+// even load there ("version `hip_7.1' not found").  kUnknownStreamId when the runtime has no such call or will not say: identity
+// then cannot be proven by id, and workspace_acquire falls back on asking the live stream whether it is idle (see there).
 constexpr unsigned long long kUnknownStreamId = ~0ull;
+using StreamGetIdFn = hipError_t (*)(hipStream_t, unsigned long long*);
+inline StreamGetIdFn stream_get_id_fn()
+{
+    static const StreamGetIdFn fn = [] {
+        void* h = dlopen("libamdhip64.so.7", RTLD_NOLOAD | RTLD_NOW);   // the copy this process is already bound to, by soname
+        void* sym = h ? dlsym(h, "hipStreamGetId") : nullptr;
+        if (!sym) sym = dlsym(RTLD_DEFAULT, "hipStreamGetId");
+        return reinterpret_cast<StreamGetIdFn>(sym);
+    }();
+    return fn;
+}
 inline unsigned long long stream_identity(hipStream_t s)
 {
+    const StreamGetIdFn fn = stream_get_id_fn();
     unsigned long long id = 0;
-    if (hipStreamGetId(s, &id) != hipSuccess) { (void)hipGetLastError(); return kUnknownStreamId; }
+    if (!fn) return kUnknownStreamId;
+    if (fn(s, &id) != hipSuccess) { (void)hipGetLastError(); return kUnknownStreamId; }
     return id;
+}
+
+// Is the call on live stream `s` certainly ordered behind the outstanding tickets, i.e. is `s` THE stream they were issued on?
+// The same address is necessary, not sufficient: a stream destroyed with work in flight and a new one created in its place are two
+// streams.  Where the runtime numbers its streams, the number decides.  Where it does not (HIP 7.0), the live stream
+// is asked whether it is idle: an idle stream orders nothing — either it is the old one and everything has retired, or it is a
+// new one at the old address — so the stamps decide; a busy stream at the same address is taken for the old one (what is left
+// open on such a runtime: a NEW stream at the old address on which the caller has already queued work of its own).
+inline bool workspace_same_stream(c2d_ctx* ctx, hipStream_t s)
+{
+    if (ctx->ws_stream != s) return false;
+    if (ctx->ws_stream_id != kUnknownStreamId) return stream_identity(s) == ctx->ws_stream_id;
+    const hipError_t q = hipStreamQuery(s);
+    (void)hipGetLastError();                 // (hipErrorNotReady is an answer, not an error to find at the next launch check)
+    return q == hipErrorNotReady;
 }
 
 inline int workspace_acquire(c2d_ctx* ctx, hipStream_t s, bool uses)
@@ -145,7 +177,7 @@ inline int workspace_acquire(c2d_ctx* ctx, hipStream_t s, bool uses)
     if (!uses || !ctx->ws_outstanding) return C2D_OK;
     // the same stream as the outstanding tickets': the stream orders the calls.  The same ADDRESS is not enough — a stream destroyed
     // with work in flight and a new one created in its place are two streams.
-    if (ctx->ws_stream == s && ctx->ws_stream_id != kUnknownStreamId && stream_identity(s) == ctx->ws_stream_id) return C2D_OK;
+    if (workspace_same_stream(ctx, s)) return C2D_OK;
     if (stream_is_capturing(s)) return C2D_OK;
     if (!ctx->ws_probe_stream) {
         hipError_t e = hipStreamCreateWithFlags(&ctx->ws_probe_stream, hipStreamNonBlocking);
@@ -251,7 +283,9 @@ struct WorkspaceUse {
 // `s` has been synchronised by the caller: if it is the stream the outstanding tickets were issued on, they have retired.
 inline void workspace_stream_drained(c2d_ctx* ctx, hipStream_t s)
 {
-    if (ctx->ws_outstanding && ctx->ws_stream == s && stream_identity(s) == ctx->ws_stream_id && ctx->ws_stream_id != kUnknownStreamId)
+    // (by id only: without ids a drained stream at the tickets' address may as well be a new stream created where theirs was, and
+    // the next counted call finds out from the stamps — one read of the workspace block, on a runtime without hipStreamGetId)
+    if (ctx->ws_outstanding && ctx->ws_stream == s && ctx->ws_stream_id != kUnknownStreamId && stream_identity(s) == ctx->ws_stream_id)
         ctx->ws_outstanding = false;
 }
 

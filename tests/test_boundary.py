@@ -145,3 +145,33 @@ def test_no_kernel_selects_on_a_stale_scalar_condition():
     libs.append(os.path.join(PKG_DIR, "lib-rehearsal", "libc2d.so"))
     for lib in libs:
         assert scc.scan_library(lib) == [], lib
+
+
+def test_shipped_libraries_load_beside_pytorchs_hip_runtime():
+    """A PyTorch process has loaded PyTorch's own libamdhip64.so.7 (HIP 7.0 here) before libc2d.so, and the dynamic loader binds
+    libc2d.so to THAT copy: a library that needs a symbol version newer than it defines does not load there at all ("version
+    `hip_7.1' not found": round 6 met it with hipStreamGetId, which is now looked up at run time, csrc/c2d_internal.hpp).  Every
+    shipped build may need only versioned HIP symbols that PyTorch's runtime defines."""
+    import glob
+    import importlib.util
+
+    spec = importlib.util.find_spec("torch")
+    torch_hip = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    assert os.path.exists(torch_hip)
+
+    def versions(path, defined):
+        out = subprocess.run(["objdump", "-T", path], capture_output=True, text=True, check=True).stdout
+        found = set()
+        for ln in out.splitlines():
+            m = re.search(r"\((hip_[0-9.]+)\)|\s(hip_[0-9.]+)\s", ln)
+            if m and (("*UND*" in ln) != defined):
+                found.add(m.group(1) or m.group(2))
+        return found
+
+    provides = versions(torch_hip, True)
+    assert "hip_4.2" in provides and len(provides) >= 4, provides
+    libs = glob.glob(os.path.join(PKG_DIR, "lib", "libc2d*.so")) + [os.path.join(PKG_DIR, "lib-rehearsal", "libc2d.so")]
+    assert len(libs) >= 6
+    for lib in libs:
+        needs = versions(lib, False)
+        assert needs and needs <= provides, (lib, sorted(needs - provides))
