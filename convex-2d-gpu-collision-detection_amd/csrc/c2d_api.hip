@@ -214,7 +214,10 @@ int c2d_stream_destroy(c2d_ctx* ctx, c2d_stream stream)
     if (!ctx) return C2D_ERR_INVALID_ARG;
     if (!stream) return C2D_OK;
     c2d::DeviceGuard g(ctx->device);
-    C2D_HIP(ctx, hipStreamDestroy((hipStream_t)stream));  // (the workspace guard never touches a stream handle: c2d_internal.hpp)
+    // The guard never hands a remembered stream to the runtime, and destroying a stream with calls queued is legal: they finish.
+    // But its ADDRESS may be given to the next stream created, and then must not pass for the stream of the outstanding tickets.
+    if (ctx->ws_outstanding && ctx->ws_stream == (hipStream_t)stream) ctx->ws_stream = c2d::forgotten_stream();
+    C2D_HIP(ctx, hipStreamDestroy((hipStream_t)stream));
     return C2D_OK;
 }
 

@@ -157,20 +157,24 @@ inline unsigned long long stream_identity(hipStream_t s)
     return id;
 }
 
-// Is the call on live stream `s` certainly ordered behind the outstanding tickets, i.e. is `s` THE stream they were issued on?
+// Is the call on live stream `s` ordered behind the outstanding tickets, i.e. is `s` THE stream they were issued on?
 // The same address is necessary, not sufficient: a stream destroyed with work in flight and a new one created in its place are two
-// streams.  Where the runtime numbers its streams, the number decides.  Where it does not (HIP 7.0), the live stream
-// is asked whether it is idle: an idle stream orders nothing — either it is the old one and everything has retired, or it is a
-// new one at the old address — so the stamps decide; a busy stream at the same address is taken for the old one (what is left
-// open on such a runtime: a NEW stream at the old address on which the caller has already queued work of its own).
+// streams.  Where the runtime numbers its streams, the number decides.  Where it does not (HIP 7.0: a PyTorch process)
+// the address is all there is: c2d_stream_destroy then forgets the address of a stream it destroys with tickets outstanding
+// (kForgottenStream, below), and what stays open is a stream destroyed BEHIND the ctx's back with work in flight whose address
+// the runtime hands to a new stream that the caller uses at once — include/c2d.h says so.  (Asking the live stream whether it is
+// idle — hipStreamQuery on the caller's own handle, an idle stream orders nothing so the stamps decide — closes all but a corner
+// of that, and costs 3 % of the headline kernel: the runtime puts a marker behind the last kernel to answer.
+// profiles/r06_idle_query_ab.txt; not shipped.)
 inline bool workspace_same_stream(c2d_ctx* ctx, hipStream_t s)
 {
     if (ctx->ws_stream != s) return false;
     if (ctx->ws_stream_id != kUnknownStreamId) return stream_identity(s) == ctx->ws_stream_id;
-    const hipError_t q = hipStreamQuery(s);
-    (void)hipGetLastError();                 // (hipErrorNotReady is an answer, not an error to find at the next launch check)
-    return q == hipErrorNotReady;
+    return true;
 }
+
+// what ws_stream holds once c2d_stream_destroy has destroyed the stream of the outstanding tickets: no live stream's address
+inline hipStream_t forgotten_stream() { return reinterpret_cast<hipStream_t>(~static_cast<uintptr_t>(0)); }
 
 inline int workspace_acquire(c2d_ctx* ctx, hipStream_t s, bool uses)
 {
@@ -283,9 +287,7 @@ struct WorkspaceUse {
 // `s` has been synchronised by the caller: if it is the stream the outstanding tickets were issued on, they have retired.
 inline void workspace_stream_drained(c2d_ctx* ctx, hipStream_t s)
 {
-    // (by id only: without ids a drained stream at the tickets' address may as well be a new stream created where theirs was, and
-    // the next counted call finds out from the stamps — one read of the workspace block, on a runtime without hipStreamGetId)
-    if (ctx->ws_outstanding && ctx->ws_stream == s && ctx->ws_stream_id != kUnknownStreamId && stream_identity(s) == ctx->ws_stream_id)
+    if (ctx->ws_outstanding && workspace_same_stream(ctx, s))
         ctx->ws_outstanding = false;
 }
 

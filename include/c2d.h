@@ -22,10 +22,17 @@
  *     Streams stay the caller's: c2d keeps no stream handle beyond the call it was given to
  *     (the guard reads completion stamps that the kernels raise themselves, never the
  *     runtime's view of a remembered stream), so a stream may be destroyed by any means at
- *     any time after its calls were issued.  While a stream is being captured into a graph
- *     the guard stands aside: the order of a graph's replays against other work on the same
- *     ctx is the caller's to arrange.  Should a launch ever fail after it took its place in
- *     the guard's bookkeeping, c2d_stream_synchronize on that stream resets it.
+ *     any time after its calls were issued.  A NEW stream that the runtime creates at a
+ *     destroyed stream's address is another stream to the guard, not the old one: it compares
+ *     hipStreamGetId where the runtime has it (HIP >= 7.1).  On an older runtime — the HIP 7.0
+ *     a PyTorch process holds — streams have no number: c2d_stream_destroy forgets the address
+ *     of a stream it destroys with calls in flight, but a stream destroyed by OTHER means with
+ *     c2d calls still in flight, whose address the runtime gives to a new stream that is used
+ *     with the same ctx at once, passes for the old one there: drain such a stream first (or
+ *     destroy it through c2d_stream_destroy).  While a stream is being captured into a
+ *     graph the guard stands aside: the order of a graph's replays against other work on the
+ *     same ctx is the caller's to arrange.  A launch that fails after it took its place in the
+ *     guard's bookkeeping takes itself out again (the failing call drains its stream).
  *
  * Arithmetic contract (DESIGN.md §"Canonical arithmetic"): IEEE binary32,
  * round-to-nearest-even, no multiply-add contraction except where the spec

@@ -3,10 +3,12 @@ a separate process by tests/test_gpu_workspace_guard.py:   stream_alias_check.py
 
   rocm     libc2d.so binds ROCm's libamdhip64.so.7 (hipStreamGetId exists: the stream's number decides);
   pytorch  torch is imported first, so the process holds the libamdhip64.so.7 PyTorch ships (HIP 7.0 in this image: no
-           hipStreamGetId; the guard asks the live stream whether it is idle and lets the stamps decide).
+           hipStreamGetId; the address is all the guard has, and c2d_stream_destroy forgets the address of a stream it
+           destroys with tickets outstanding — include/c2d.h names what stays open for streams destroyed by other means).
 
-An adaptive call (milliseconds of work) is queued on a stream, the stream destroyed through the runtime behind c2d's back, new
-streams created until the address repeats, and a counted call issued on that alias: it must be refused while the adaptive call is
+An adaptive call (milliseconds of work) is queued on a stream, the stream destroyed — through the runtime, behind c2d's back,
+where the runtime numbers its streams; through c2d_stream_destroy where it does not — new streams created until the address
+repeats, and a counted call issued on that alias: it must be refused while the adaptive call is
 certainly still running, give the oracle's count once the device has drained, and never disturb the adaptive call's rows.
 TEST INFRASTRUCTURE: uses the oracle as the checker."""
 import ctypes as C
@@ -66,7 +68,10 @@ def main():
         sa = stream()
         t0 = time.perf_counter()
         eng.mc_scenes_async(d_p, 64, d_s, 64, d_sc, ns, 4.07, 1.74, wl.DEFAULT_BINS, wl.DEFAULT_BIN_ACCURACY, 400_000, 3, 0, d_h, d_u, stream=sa)
-        assert hip.hipStreamDestroy(C.c_void_p(sa)) == 0      # behind c2d's back, with the adaptive call in flight
+        if has_id:
+            assert hip.hipStreamDestroy(C.c_void_p(sa)) == 0  # behind c2d's back, with the adaptive call in flight
+        else:
+            eng.stream_destroy(sa)                             # (no stream numbers: c2d must be told, include/c2d.h)
         others, alias = [], None
         for _ in range(256):                                   # create streams until the address repeats
             t = stream()
