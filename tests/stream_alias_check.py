@@ -68,10 +68,12 @@ def main():
         sa = stream()
         t0 = time.perf_counter()
         eng.mc_scenes_async(d_p, 64, d_s, 64, d_sc, ns, 4.07, 1.74, wl.DEFAULT_BINS, wl.DEFAULT_BIN_ACCURACY, 400_000, 3, 0, d_h, d_u, stream=sa)
+        t_queued = time.perf_counter() - t0
         if has_id:
             assert hip.hipStreamDestroy(C.c_void_p(sa)) == 0  # behind c2d's back, with the adaptive call in flight
         else:
             eng.stream_destroy(sa)                             # (no stream numbers: c2d must be told, include/c2d.h)
+        t_destroyed = time.perf_counter() - t0
         others, alias = [], None
         for _ in range(256):                                   # create streams until the address repeats
             t = stream()
@@ -91,6 +93,8 @@ def main():
                 refused_on_alias += 1
         assert hip.hipDeviceSynchronize() == 0
         t_all = time.perf_counter() - t0
+        print(f"  attempt {attempt}: call queued after {t_queued * 1e3:.2f} ms, stream destroyed after {t_destroyed * 1e3:.2f} ms, address repeated after "
+              f"{len(others)} other streams at {(t_alias or 0) * 1e3:.2f} ms, alias call {'refused' if was_refused else 'accepted'}, device drained at {t_all * 1e3:.2f} ms")
         if t_alias is not None and t_alias < 0.5 * t_all:      # the adaptive call was certainly still running when the alias call came
             early += 1
             assert was_refused, ("a counted call on the alias passed while the adaptive call was running", attempt, t_alias, t_all, has_id)
