@@ -178,6 +178,7 @@ inline hipStream_t forgotten_stream() { return reinterpret_cast<hipStream_t>(~st
 
 inline int workspace_acquire(c2d_ctx* ctx, hipStream_t s, bool uses)
 {
+    ctx->ws_ticket_pending = false;   // (a new call: whatever ticket an earlier call took has had its launch check)
     if (!uses || !ctx->ws_outstanding) return C2D_OK;
     // the same stream as the outstanding tickets': the stream orders the calls.  The same ADDRESS is not enough — a stream destroyed
     // with work in flight and a new one created in its place are two streams.
