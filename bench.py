@@ -105,6 +105,17 @@ def self_launch(n_gpus: int) -> int:
     import socket
     import subprocess
 
+    # Starting the ranks is a fork + exec.  That is only safe from a process that has not initialised the GPU — this one has not, of
+    # its own — but a profiler / tool library preloaded into it (rocprofv3 puts its own into every process it starts) has, before
+    # main, and an exec from such a process is what this pool's hosts forbid.  Same rule as the drivers' --gpus N.
+    for var in ("ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_LIBRARY", "LD_PRELOAD"):
+        val = os.environ.get(var, "")
+        if val and (var != "LD_PRELOAD" or any(nm in val.lower() for nm in ("rocprof", "roctracer", "roctx", "libhsa", "libamdhip"))):
+            sys.stderr.write(f"[bench] --gpus {n_gpus} refused: a profiler / tool library is preloaded into this process ({var}={val}); the "
+                             "launcher would have to exec its ranks from a process that holds the GPU.  Profile ONE rank: `rocprofv3 ... -- "
+                             "python3 bench.py` (N = 1), or one rank of a torch.distributed.run launch started by hand.\n")
+            return 2
+
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
