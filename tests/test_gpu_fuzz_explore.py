@@ -1,6 +1,6 @@
 """The exploring legs of the differential fuzzers: the same generators as the fixed-seed legs (test_gpu_sat.py
 test_poly_differential_fuzz, test_gpu_mc.py test_mc_differential_fuzz, test_gpu_poly_binned.py test_binned_differential_fuzz,
-tests/tools/pose_fuzz.py), seeded from the commit under test (tests/tools/fuzz_seed.py) and run for a time budget instead of
+tests/tools/pose_fuzz.py; and tests/tools/verts_fuzz.py for the headline vertex-format entry points), seeded from the commit under test (tests/tools/fuzz_seed.py) and run for a time budget instead of
 a configuration count, so that every run of the suite at a new commit meets inputs no earlier run has met.  Round 5's one
 defect — the binning pass's move kernel reading past its arrays on a last partial tile — passed two green runs of the
 fixed-seed suite and was met by a soak outside it (profiles/notes_r05_move_kernel_overread.md).
@@ -8,7 +8,7 @@ fixed-seed suite and was met by a soak outside it (profiles/notes_r05_move_kerne
 Every leg prints its seed BEFORE it starts (past pytest's capture: a GPU fault takes the captured output down with the
 process) and names every configuration, before it runs, in gpurun_out/fuzz_trace/<leg>.txt.  To reproduce a failure:
     C2D_FUZZ_SEED=<base seed printed> python -m pytest tests/test_gpu_fuzz_explore.py -m gpu -k <leg>
-($C2D_FUZZ_SECONDS, default 50, is each leg's budget; a configuration is a function of (seed, its index) alone.)"""
+($C2D_FUZZ_SECONDS, default 40, is each leg's budget; a configuration is a function of (seed, its index) alone.)"""
 import importlib.util
 import os
 import time
@@ -20,8 +20,8 @@ pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-LEGS = ("sat_rect_pose", "sat_poly_rows", "sat_poly_binned", "mc_scenes")
-TOOL = {"sat_rect_pose": "pose_fuzz", "sat_poly_rows": "poly_fuzz", "sat_poly_binned": "binned_fuzz", "mc_scenes": "mc_fuzz"}
+LEGS = ("sat_rect_pose", "sat_poly_rows", "sat_poly_binned", "mc_scenes", "sat_rect_verts")   # (append only: a leg's seed offset is its index)
+TOOL = {"sat_rect_verts": "verts_fuzz", "sat_rect_pose": "pose_fuzz", "sat_poly_rows": "poly_fuzz", "sat_poly_binned": "binned_fuzz", "mc_scenes": "mc_fuzz"}
 
 
 def _tool(name):
@@ -35,7 +35,7 @@ def _tool(name):
 def test_differential_fuzz_at_this_commits_seed(eng, capsys, leg):
     base, origin = _tool("fuzz_seed").commit_seed()
     seed = (base + 0x3C6EF35F * LEGS.index(leg)) & 0x7FFFFFFF   # one stream per leg
-    budget = float(os.environ.get("C2D_FUZZ_SECONDS", "50"))
+    budget = float(os.environ.get("C2D_FUZZ_SECONDS", "40"))
     fz = _tool(TOOL[leg])
     trace_dir = os.path.join(ROOT, "gpurun_out", "fuzz_trace")
     try:
