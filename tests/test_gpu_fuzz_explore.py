@@ -32,7 +32,7 @@ def _tool(name):
 
 
 @pytest.mark.parametrize("leg", LEGS)
-def test_differential_fuzz_at_this_commits_seed(eng, capsys, leg):
+def test_differential_fuzz_at_this_commits_seed(eng, oracle, capsys, leg):   # (`oracle`: sizes the OpenMP team to the box's CPU share)
     base, origin = _tool("fuzz_seed").commit_seed()
     seed = (base + 0x3C6EF35F * LEGS.index(leg)) & 0x7FFFFFFF   # one stream per leg
     budget = float(os.environ.get("C2D_FUZZ_SECONDS", "40"))
