@@ -135,7 +135,7 @@ inline bool stream_is_capturing(hipStream_t s)
 // hipStreamGetId exists since HIP 7.1 and is looked up in the libamdhip64 this process already holds, not linked: a PyTorch process
 // has loaded PyTorch's own libamdhip64.so.7 (HIP 7.0 in this image) before libc2d.so, and a library that NEEDS the symbol does not
 // even load there ("version `hip_7.1' not found").  kUnknownStreamId when the runtime has no such call or will not say: identity
-// then cannot be proven by id, and workspace_acquire falls back on asking the live stream whether it is idle (see there).
+// then cannot be proven by id, and the address alone decides (workspace_same_stream below says what that leaves open).
 constexpr unsigned long long kUnknownStreamId = ~0ull;
 using StreamGetIdFn = hipError_t (*)(hipStream_t, unsigned long long*);
 inline StreamGetIdFn stream_get_id_fn()
@@ -161,7 +161,7 @@ inline unsigned long long stream_identity(hipStream_t s)
 // The same address is necessary, not sufficient: a stream destroyed with work in flight and a new one created in its place are two
 // streams.  Where the runtime numbers its streams, the number decides.  Where it does not (HIP 7.0: a PyTorch process)
 // the address is all there is: c2d_stream_destroy then forgets the address of a stream it destroys with tickets outstanding
-// (kForgottenStream, below), and what stays open is a stream destroyed BEHIND the ctx's back with work in flight whose address
+// (forgotten_stream, below), and what stays open is a stream destroyed BEHIND the ctx's back with work in flight whose address
 // the runtime hands to a new stream that the caller uses at once — include/c2d.h says so.  (Asking the live stream whether it is
 // idle — hipStreamQuery on the caller's own handle, an idle stream orders nothing so the stamps decide — closes all but a corner
 // of that, and costs 3 % of the headline kernel: the runtime puts a marker behind the last kernel to answer.
