@@ -18,5 +18,14 @@ for S in ${SEEDS:-601 602}; do
     rc=${PIPESTATUS[0]}
     [ $rc -ne 0 ] && { echo "$1 rc=$rc at seed $S: stopping"; exit $rc; }
   done
+  # the binning pass on its index-checked build (make lib-movecheck): every index the move kernel forms is compared with its array's
+  # size and the first offender reported on stderr instead of being used — reads past an input cannot be seen from results
+  echo "### binned_fuzz 600 $S on libc2d_movecheck.so"
+  C2D_LIBRARY=$PWD/convex-2d-gpu-collision-detection_amd/lib/libc2d_movecheck.so timeout -k 10 ${LIMIT:-280} python3 $T/binned_fuzz.py 600 $S > /tmp/movecheck_$S.log 2>&1
+  rc=$?
+  tail -1 /tmp/movecheck_$S.log
+  echo "index reports: $(grep -c 'c2d move check' /tmp/movecheck_$S.log)"
+  [ $rc -ne 0 ] && { echo "binned_fuzz on the index-checked build rc=$rc at seed $S: stopping"; exit $rc; }
+  grep -q 'c2d move check' /tmp/movecheck_$S.log && { echo "the index-checked build reported an access outside its arrays at seed $S: stopping"; grep 'c2d move check' /tmp/movecheck_$S.log | head -5; exit 9; }
 done
 echo "# done: 0 differences"
