@@ -355,30 +355,15 @@ def setup(args, R) -> None:
     # ---- what makes an N > 1 line readable: every rank's own kernel time, and the closing reduce by itself ----
     on_device = args.backend == "nccl"
 
-    def gather_ranks(vals):
-        """Every rank's row of a few doubles, in rank order: ONE all_gather, always AFTER a timed region."""
-        if not use_dist:
-            return [[float(v) for v in vals]]
-        t = torch.tensor([float(v) for v in vals], dtype=torch.float64, device=dev if on_device else None)
-        rows = [torch.empty_like(t) for _ in range(dist.get_world_size())]
-        dist.all_gather(rows, t)
-        return [r.tolist() for r in rows]
-
     def rank_spread(kernel_ms, units, roofline=None, work=None):
-        """kernel_ms = this rank's HIP-event time of one launch (or of the leg's one device loop), units = what that launch processed
-        on this rank, work = what its roofline counts when that is not the unit (drawn samples of an adaptive loop).  Returns
-        ({min, median, max, ...} of kernel_ms over ranks, sum of units / slowest rank's time) and writes `kernel_ms_ranks` and
-        `frac_slowest_rank` into the roofline: `frac` is rank 0's, a curve is bounded by the slowest rank's."""
-        rows = gather_ranks([kernel_ms, units, units if work is None else work])
-        ms = np.array([r[0] for r in rows])
-        slow = int(ms.argmax())
-        spread = {"min": round(float(ms.min()), 5), "median": round(float(np.median(ms)), 5), "max": round(float(ms.max()), 5),
-                  "ranks": len(rows), "slowest_rank": slow}
-        kernels_only = sum(r[1] for r in rows) / (float(ms.max()) * 1e-3) if ms.max() > 0 else None
+        """Every rank's own kernel time (c2d_amd.sharding.kernel_time_spread: one all_gather AFTER the timed region): returns
+        ({min, median, max, ...} of kernel_ms over ranks, all ranks' units / the slowest rank's time) and writes `kernel_ms_ranks` and
+        `frac_slowest_rank` into the roofline — `frac` is rank 0's, a curve is bounded by the slowest rank's."""
+        spread, kernels_only, frac_slowest = shd.kernel_time_spread(kernel_ms, units, roofline["frac"] if roofline is not None else None, work,
+                                                                    dev if on_device else None)
         if roofline is not None:
-            me = rows[rank if use_dist else 0]
             roofline["kernel_ms_ranks"] = spread
-            roofline["frac_slowest_rank"] = round(roofline["frac"] * (rows[slow][2] / me[2]) * (me[0] / rows[slow][0]), 4) if me[2] and rows[slow][0] else None
+            roofline["frac_slowest_rank"] = frac_slowest
         return spread, kernels_only
 
     def time_reduce(numel=1, before=None, reps=20):

@@ -63,8 +63,12 @@ def _worker(rank, world, port, q):
     h, u, _, tot = oracle.mc_scenes(tp, ts, scenes[sb:se], 4.07, 1.74, [0, .01, .1, 1], [1e-4, 1e-3, 1e-2], 2000, 8, sb)
     scene_hits, scene_samples = sh.all_reduce_counters([int(h.sum()), tot])
     tmax = sh.max_over_ranks(1.0 + rank)
+    # (4) what bench.py adds to an N > 1 line: every rank's kernel time in rank order, the rate of the kernels alone and
+    # the slowest rank's roofline fraction.  Rank r "measures" 0.1 + 0.01 r ms on 1000 + r units of which 10 (r + 1) count as work.
+    rows = sh.gather_rows([rank, 10.0 * rank])
+    spread, kernels_only, frac_slowest = sh.kernel_time_spread(0.1 + 0.01 * rank, 1000 + rank, frac=0.5, work=10 * (rank + 1))
     if rank == 0:
-        q.put((hits, samples, total_cnt, scene_hits, scene_samples, tmax))
+        q.put((hits, samples, total_cnt, scene_hits, scene_samples, tmax, rows, spread, kernels_only, frac_slowest))
     dist.destroy_process_group()
 
 
@@ -99,7 +103,14 @@ def test_gloo_sharding_reproduces_single_process(oracle, wl, world):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    hits, samples, total_cnt, scene_hits, scene_samples, tmax = res
+    hits, samples, total_cnt, scene_hits, scene_samples, tmax, rows, spread, kernels_only, frac_slowest = res
+    assert rows == [[float(r), 10.0 * r] for r in range(world)]                       # rank order
+    slowest = world - 1
+    assert spread["ranks"] == world and spread["slowest_rank"] == slowest
+    assert spread["min"] == 0.1 and spread["max"] == round(0.1 + 0.01 * slowest, 5) and spread["min"] <= spread["median"] <= spread["max"]
+    assert abs(kernels_only - sum(1000 + r for r in range(world)) / ((0.1 + 0.01 * slowest) * 1e-3)) < 1e-3
+    # rank 0's fraction 0.5 (10 work units in 0.1 ms) rescaled to the slowest rank's work and time
+    assert frac_slowest == round(0.5 * (10 * world / 10) * (0.1 / (0.1 + 0.01 * slowest)), 4)
     sc = wl.MC_PAIR_SCENE
     assert samples == 200_001
     assert hits == oracle.mc_pair(sc["robot_w"], sc["robot_h"], sc["pos"], sc["pose"], sc["std_dev"], 1234, 0, 0, 200_001)
