@@ -104,6 +104,25 @@ def test_self_launch_is_refused_under_a_preloaded_profiler(tmp_path):
     assert "--gpus" in run([GEN, "--help"]).stdout and "never the launcher" in run([GEN, "--help"]).stdout
 
 
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/rocprofv3"), reason="needs rocprofv3")
+def test_self_launch_is_refused_under_the_real_rocprofv3(tmp_path):
+    """The same with the profiler itself in front, not a hand-set variable: what rocprofv3 puts into its child's environment is what
+    the launchers look for — the driver's `--gpus N` and `bench.py --gpus N` both refuse, and rocprofv3 hands their status on."""
+    import sys
+
+    env = dict(os.environ, TMPDIR=str(tmp_path))
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None)
+    prof = ["/opt/rocm/bin/rocprofv3", "--kernel-trace", "-d", str(tmp_path / "prof"), "--"]
+    out = subprocess.run(prof + [GEN, "--data_dir", str(tmp_path / "d"), "--gpus", "2", "-n", "2", "-b", "10"], capture_output=True, text=True,
+                         timeout=120, env=env, cwd=str(tmp_path))
+    assert out.returncode != 0 and "--gpus 2 refused" in out.stderr and "rocprofiler" in out.stderr, out.stderr[-2000:]
+    assert not (tmp_path / "d").exists() and not list(tmp_path.glob("c2d_dist_id_*"))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run(prof + [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120,
+                         env=env, cwd=str(tmp_path))
+    assert out.returncode != 0 and "--gpus 2 refused" in out.stderr and not [ln for ln in out.stdout.splitlines() if ln.startswith("{")], out.stderr[-2000:]
+
+
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="CPU-only behaviour")
 def test_self_launched_ranks_propagate_failure_without_gpu(tmp_path):
     """--gpus N: the launcher starts N fresh copies of itself and returns the first non-zero exit status; without a GPU every
