@@ -28,7 +28,8 @@ def main():
     eng = pkg.Engine(0)
     dev = torch.device("cuda", 0)
     n = 10_000_000
-    vx, vy, kk = torch_random_convex_polygons(torch, dev, n, seed=0xC0FFEE)
+    seed = int(os.environ.get("C2D_FULLSIZE_SEED", "0xC0FFEE"), 0)    # (another seed: profiles/r06_fullsize_seeds.sh)
+    vx, vy, kk = torch_random_convex_polygons(torch, dev, n, seed=seed)
     torch.cuda.synchronize()
 
     def run(ax, ay, ak):
@@ -62,7 +63,7 @@ def main():
     assert ref.shape == got.shape == (n,)
     assert np.array_equal(got, ref) and ref_cnt == cnt
     eng.check_async()
-    print(f"fullsize poly ok: {n} pairs, {cnt} colliding, booleans equal to the oracle's on {int((got == ref).sum())} of {n}")
+    print(f"fullsize poly ok (seed {seed}): {n} pairs, {cnt} colliding, booleans equal to the oracle's on {int((got == ref).sum())} of {n}")
 
 
 if __name__ == "__main__":

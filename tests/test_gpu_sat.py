@@ -167,7 +167,7 @@ def test_full_size_1e7_oracle_equality_and_properties(eng, oracle, wl):
     collide(a,b) == collide(b,a); collide is invariant under a cyclic shift of
     either vertex list; the device count equals the sum of the booleans."""
     n = 10_000_000
-    poses = wl.random_obb_pose_planes(n, seed=0x5A7)
+    poses = wl.random_obb_pose_planes(n, seed=int(os.environ.get("C2D_FULLSIZE_SEED", "0x5A7"), 0))   # (another seed: profiles/r06_fullsize_seeds.sh)
     d_pose = eng.to_device(poses)
     del poses
     d_planes = eng.empty((16, n), np.float32)
