@@ -34,10 +34,11 @@ def _scenes_run(e, pkg, d_p, d_s, d_sc_ptr, ns, base, max_samples=120_000):
 
 def test_config4_shard_at_full_size(eng, pkg, oracle, wl):
     ns = 4_000_000
-    tp, ts, _ = wl.random_tables(65536, 65536, seed=7)
+    seed = int(os.environ.get("C2D_FULLSIZE_SEED", "7"), 0)   # tables and scenes of another seed: profiles/r06_fullsize_seeds.sh
+    tp, ts, _ = wl.random_tables(65536, 65536, seed=seed)
     d_p, d_s = eng.to_device(tp), eng.to_device(ts)
     d_sc = eng.empty(ns, pkg.SCENE_DT)
-    eng.sample_scenes(d_p, 65536, d_s, 65536, 4.07, 1.74, 4.0, 7, 0, ns, d_sc)
+    eng.sample_scenes(d_p, 65536, d_s, 65536, 4.07, 1.74, 4.0, seed, 0, ns, d_sc)
     h, u, total, iters = _scenes_run(eng, pkg, d_p, d_s, d_sc, ns, 0)
     assert total == int(u.astype(np.int64).sum())
     assert iters >= 20 and int(u.max()) >= 120_000 and int(u.min()) == 1000      # early stoppers and scenes run to the cap

@@ -189,7 +189,7 @@ def test_mc_pair_1e8_vs_oracle_exact(eng, oracle, wl):
     (the loop of ccp.cu:135-139 over utils.cu:144-184; the OpenMP oracle walks 1e8 samples in a second or two), and so do the
     counts of an unaligned split of the same range (what two ranks would add up)."""
     sc = wl.MC_PAIR_SCENE
-    args = (sc["pos"], sc["pose"], sc["std_dev"], 1234, 0)
+    args = (sc["pos"], sc["pose"], sc["std_dev"], int(os.environ.get("C2D_FULLSIZE_SEED", "1234"), 0), 0)   # (another stream: profiles/r06_fullsize_seeds.sh)
     n = 100_000_000
     ref = oracle.mc_pair(W, H, *args, 0, n)
     got = gpu_hits(eng, *args, 0, n)
